@@ -1,0 +1,174 @@
+r"""Device tree engine handle: the Python face of the `bbh_tree_*` C ABI.
+
+`BitBirch` (bitbirch.py) owns the host-side bookkeeping (molecule-index lists, dtype
+groups, refine orchestration) and talks to the HBM-resident tree only through the five
+operations below.  Tests exercise the same host logic against the CPU oracle by
+injecting an object with the same methods (tests/oracle_engine.py); the product never
+does that - `HipEngine` is the only engine the package constructs.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+from numpy.typing import NDArray
+
+from bblean_amd import _lib
+
+_WIDTH_DTYPES = {1: np.uint8, 2: np.uint16, 4: np.uint32, 8: np.uint64}
+
+
+def _is_device_tensor(x: object) -> bool:
+    return hasattr(x, "data_ptr") and getattr(x, "is_cuda", False)
+
+
+class HipEngine:
+    r"""One BitBIRCH tree resident in the HBM of one MI355X."""
+
+    def __init__(
+        self,
+        branching_factor: int,
+        threshold: float,
+        criterion: int,
+        tolerance: float,
+        tol_table: NDArray[np.float64],
+        n_features: int,
+        device: int = 0,
+    ) -> None:
+        self._lib = _lib.load()
+        self.n_features = int(n_features)
+        self.nbytes = (self.n_features + 7) // 8
+        self._h = C.c_void_p()
+        tab = np.ascontiguousarray(tol_table, dtype=np.float64)
+        _lib.check(
+            self._lib.bbh_tree_create(
+                C.byref(self._h),
+                int(branching_factor),
+                float(threshold),
+                int(criterion),
+                float(tolerance),
+                tab.ctypes.data if tab.size else None,
+                tab.size,
+                self.n_features,
+                int(device),
+            )
+        )
+
+    # -- configuration ---------------------------------------------------------------
+    def set_merge(
+        self,
+        criterion: int,
+        tolerance: float,
+        tol_table: NDArray[np.float64],
+        threshold: float,
+        branching_factor: int,
+    ) -> None:
+        tab = np.ascontiguousarray(tol_table, dtype=np.float64)
+        _lib.check(
+            self._lib.bbh_tree_set_merge(
+                self._h,
+                int(criterion),
+                float(tolerance),
+                tab.ctypes.data if tab.size else None,
+                tab.size,
+                float(threshold),
+                int(branching_factor),
+            )
+        )
+
+    def reset(self) -> None:
+        _lib.check(self._lib.bbh_tree_reset(self._h))
+
+    # -- insertion -------------------------------------------------------------------
+    def fit_packed(self, rows: object, stream: int | None = None) -> NDArray[np.uint32]:
+        r"""Insert packed fingerprints (numpy uint8 (n, nbytes) or a CUDA/HIP torch
+        tensor of that shape, used in place).  Returns the leaf id of each element."""
+        if _is_device_tensor(rows):
+            n, nb = int(rows.shape[0]), int(rows.shape[1])  # type: ignore[attr-defined]
+            stride = int(rows.stride(0))  # type: ignore[attr-defined]
+            assert rows.stride(1) == 1  # type: ignore[attr-defined]
+            keep = rows
+        else:
+            keep = np.ascontiguousarray(rows, dtype=np.uint8)
+            n, nb = keep.shape
+            stride = nb
+        if nb != self.nbytes:
+            raise RuntimeError(f"rows have {nb} bytes, tree expects {self.nbytes}")
+        out = np.empty(n, dtype=np.uint32)
+        _lib.check(
+            self._lib.bbh_tree_fit_packed(
+                self._h, _lib.ptr(keep), n, stride, out.ctypes.data, stream
+            )
+        )
+        return out
+
+    def fit_buffers(self, bufs: NDArray[np.integer], stream: int | None = None) -> NDArray[np.uint32]:
+        r"""Insert BitFeature buffers, shape (k, n_features + 1), unsigned dtype."""
+        bufs = np.ascontiguousarray(bufs)
+        if bufs.ndim != 2 or bufs.shape[1] != self.n_features + 1:
+            raise RuntimeError("buffers must have shape (k, n_features + 1)")
+        if bufs.dtype.kind != "u":
+            bufs = bufs.astype(np.uint64)
+        k = bufs.shape[0]
+        out = np.empty(k, dtype=np.uint32)
+        _lib.check(
+            self._lib.bbh_tree_fit_buffers(
+                self._h, bufs.ctypes.data, bufs.dtype.itemsize, k, out.ctypes.data, stream
+            )
+        )
+        return out
+
+    # -- extraction ------------------------------------------------------------------
+    def leaf_count(self) -> int:
+        k = C.c_int64(0)
+        _lib.check(self._lib.bbh_tree_leaf_count(self._h, C.byref(k)))
+        return int(k.value)
+
+    def export_leaves(
+        self, ls_width: int | None = None
+    ) -> tuple[NDArray[np.uint32], NDArray[np.uint64], NDArray[np.uint8], NDArray | None]:
+        k = self.leaf_count()
+        ids = np.empty(k, dtype=np.uint32)
+        ns = np.empty(k, dtype=np.uint64)
+        cents = np.empty((k, self.nbytes), dtype=np.uint8)
+        ls = None
+        if ls_width is not None:
+            ls = np.empty((k, self.n_features), dtype=_WIDTH_DTYPES[ls_width])
+        _lib.check(
+            self._lib.bbh_tree_export_leaves(
+                self._h,
+                ids.ctypes.data,
+                ns.ctypes.data,
+                cents.ctypes.data,
+                ls.ctypes.data if ls is not None else None,
+                ls_width or 0,
+            )
+        )
+        return ids, ns, cents, ls
+
+    def gather_buffers(self, positions: NDArray[np.int64], width: int) -> NDArray[np.integer]:
+        pos = np.ascontiguousarray(positions, dtype=np.int64)
+        out = np.empty((pos.size, self.n_features + 1), dtype=_WIDTH_DTYPES[width])
+        if pos.size:
+            _lib.check(
+                self._lib.bbh_tree_gather_buffers(
+                    self._h, pos.ctypes.data, pos.size, width, out.ctypes.data
+                )
+            )
+        return out
+
+    def stats(self) -> NDArray[np.uint64]:
+        out = np.zeros(8, dtype=np.uint64)
+        _lib.check(self._lib.bbh_tree_stats(self._h, out.ctypes.data))
+        return out
+
+    def close(self) -> None:
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.bbh_tree_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self) -> None:
+        try:
+            self.close()
+        except Exception:
+            pass

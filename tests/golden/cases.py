@@ -1,0 +1,86 @@
+r"""Case table shared by tests/golden/make_golden.py (reference side) and the parity
+tests (oracle / HIP side).  Pure data + deterministic input builders."""
+from __future__ import annotations
+
+import numpy as np
+
+SEED_B = 12620509540149709235
+
+
+def sparse_ecfp_like(n: int, n_features: int, seed: int) -> np.ndarray:
+    r"""S-ecfp: sparse rows (~48 of 2048 bits) scattered around
+    n/50 planted prototypes with ~15 % of the bits flipped.  Packed uint8."""
+    rng = np.random.default_rng(seed)
+    k = max(n // 50, 1)
+    scale = n_features / 2048.0
+    pops = np.clip(np.rint(rng.normal(48 * scale, 12 * scale, k)), 8 * scale, 160 * scale).astype(np.int64)
+    protos = np.zeros((k, n_features), dtype=bool)
+    for i in range(k):
+        protos[i, rng.choice(n_features, int(pops[i]), replace=False)] = True
+    which = rng.integers(0, k, n)
+    keep = rng.random((n, n_features)) > 0.15
+    add = rng.random((n, n_features)) < (0.15 * pops[which] / n_features)[:, None]
+    bits = (protos[which] & keep) | add
+    return np.packbits(bits.astype(np.uint8), axis=1)
+
+
+def make_input(case: dict, make_fake) -> np.ndarray:
+    kind = case.get("kind", "fake")
+    n, nf = case["n"], case["n_features"]
+    if kind == "fake":
+        return make_fake(n, n_features=nf, seed=case["seed"], pack=True)
+    if kind == "sparse":
+        return sparse_ecfp_like(n, nf, case["seed"])
+    if kind == "zeros":
+        return np.zeros((n, nf // 8), dtype=np.uint8)
+    if kind == "ones":
+        return np.full((n, nf // 8), 255, dtype=np.uint8)
+    if kind == "dups":
+        rng = np.random.default_rng(case["seed"])
+        base = rng.integers(0, 256, (7, nf // 8), dtype=np.uint8)
+        return base[rng.integers(0, 7, n)]
+    if kind == "uniform":
+        rng = np.random.default_rng(case["seed"])
+        return rng.integers(0, 256, (n, nf // 8), dtype=np.uint8)
+    raise ValueError(kind)
+
+
+def _c(name, n, bf, thr, crit, seed=SEED_B, n_features=2048, **kw):
+    d = dict(name=name, n=n, bf=bf, thr=thr, crit=crit, seed=seed, n_features=n_features)
+    d.update(kw)
+    return d
+
+
+TREE_CASES = [
+    # the reference's own end-to-end goldens (tests/test_bb_consistency.py, test_refine.py)
+    _c("diam065_3000", 3000, 50, 0.65, "diameter"),
+    _c("radius065_1000", 1000, 50, 0.65, "radius"),
+    _c("tollegacy065_500", 500, 50, 0.65, "tolerance-legacy", tol=0.05),
+    _c("refine_100", 100, 50, 0.3, "diameter", refine={}),
+    # configs of BASELINE.json at test scale
+    _c("diam03_3000", 3000, 50, 0.3, "diameter", bf_to_np=True,
+       refine={"set_merge": {"criterion": "tolerance-diameter", "tolerance": 0.05}}),
+    _c("diam03_20000", 20000, 50, 0.3, "diameter", seed=1000),
+    _c("toldiam03_3000", 3000, 50, 0.3, "tolerance-diameter", tol=0.05),
+    _c("tolradius05_1000", 1000, 50, 0.5, "tolerance-radius", tol=0.05),
+    _c("never_300", 300, 50, 0.3, "never-merge"),
+    _c("bf254_4000", 4000, 254, 0.3, "diameter", seed=77, bf_to_np=True,
+       refine={"n_largest": 3, "set_merge": {"criterion": "tolerance-diameter", "tolerance": 0.05}}),
+    _c("bf10_2000", 2000, 10, 0.4, "diameter", seed=5),
+    _c("f1024_1500", 1500, 20, 0.5, "diameter", seed=9, n_features=1024),
+    _c("f512_800", 800, 16, 0.45, "tolerance-diameter", seed=3, n_features=512, tol=0.1),
+    _c("f64_500", 500, 8, 0.5, "diameter", seed=4, n_features=64),
+    _c("diam06_dense_3000", 3000, 50, 0.6, "diameter", seed=21,
+       recluster={"iterations": 2, "extra_threshold": 0.025}),
+    _c("sparse03_5000", 5000, 50, 0.3, "diameter", kind="sparse", seed=13,
+       refine={"set_merge": {"criterion": "tolerance-diameter", "tolerance": 0.05}}),
+    _c("sparse065_3000", 3000, 50, 0.65, "diameter", kind="sparse", seed=14),
+    _c("uniform035_3000", 3000, 50, 0.35, "diameter", kind="uniform", seed=15),
+    _c("bigclusters_6000", 6000, 50, 0.2, "diameter", seed=31, bf_to_np=True,
+       refine={"set_merge": {"criterion": "tolerance-diameter", "tolerance": 0.05}}),
+    _c("zeros_10", 10, 50, 0.65, "diameter", kind="zeros"),
+    _c("ones_10", 10, 50, 0.65, "diameter", kind="ones"),
+    _c("dups_400", 400, 5, 0.65, "diameter", kind="dups", seed=8),
+    _c("splitfit_2500", 2500, 50, 0.3, "diameter", seed=41, fit_splits=[700, 1900]),
+    _c("reinsert_1000", 1000, 50, 0.3, "diameter", seed=42, reinsert_offset=5000),
+]
