@@ -1,0 +1,778 @@
+// bb_kernels.hip -- stateless similarity kernels of libbbhip.so, hand-written for
+// gfx950 (MI355X, CDNA4): wave64, 16-byte per-lane coalesced row loads, DPP row
+// reductions, popcount on the VALU (v_bcnt_u32_b32).  No MFMA: this is bit counting.
+//
+// Each extern "C" entry point replaces one pybind11 binding of the reference's
+// bblean/csrc/similarity.cpp (cited at each function and in include/bbhip.h).
+#include "bb_common.h"
+
+#include <cmath>
+
+using namespace bbd;
+
+namespace bb {
+
+thread_local char g_err[512] = "";
+bool g_prof_on = false;
+static std::mutex g_prof_mu;
+static std::vector<ProfRec> g_prof;
+
+void prof_begin(const char* name, hipStream_t s, size_t* token) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    ProfRec r;
+    r.name = name;
+    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) {
+        *token = (size_t)-1;
+        return;
+    }
+    (void)hipEventRecord(r.a, s);
+    g_prof.push_back(r);
+    *token = g_prof.size() - 1;
+}
+
+void prof_end(size_t token, hipStream_t s) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (token < g_prof.size()) (void)hipEventRecord(g_prof[token].b, s);
+}
+
+static int g_device_checked = -1;
+
+int ensure_device() {
+    if (g_device_checked >= 0) return BBH_OK;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n == 0) {
+        (void)hipGetLastError();
+        return fail(BBH_ERR_NO_DEVICE, "no HIP device visible (libbbhip has no CPU fallback)");
+    }
+    int dev = 0;
+    BB_HIP(hipGetDevice(&dev));
+    hipDeviceProp_t p;
+    BB_HIP(hipGetDeviceProperties(&p, dev));
+    if (std::strncmp(p.gcnArchName, "gfx950", 6) != 0 && getenv("BBHIP_ALLOW_ANY_ARCH") == nullptr)
+        return fail(BBH_ERR_NO_DEVICE, "device %d is %s, libbbhip is built for gfx950 only", dev,
+                    p.gcnArchName);
+    g_device_checked = dev;
+    return BBH_OK;
+}
+
+}  // namespace bb
+
+// =======================================================================================
+// K1: arr-vec Tanimoto / row popcount.  HBM-bound: 256 B read + 8 B written per row
+// at 2048 bits.  One wave owns a tile of 64 rows: LPR lanes (16 B each) cover a row,
+// 64/LPR rows per load instruction (1 KiB contiguous), all tile loads issued up front;
+// the per-row sums are reduced inside the LPR-lane group (DPP when LPR == 16) and
+// parked so that after the tile each of the 64 lanes owns one row: one f64 division
+// and one fully coalesced 512-byte store per wave.
+// =======================================================================================
+template <int LPR>
+__device__ __forceinline__ uint32_t group_sum(uint32_t v) {
+    if constexpr (LPR == 16) {
+        return row16_sum(v);
+    } else {
+#pragma unroll
+        for (int m = LPR / 2; m >= 1; m >>= 1) v += (uint32_t)__shfl_xor((int)v, m);
+        return v;
+    }
+}
+
+template <int LPR, bool HAS_VEC>
+__global__ __launch_bounds__(256) void k_arr_vec(const uint8_t* __restrict__ arr, int64_t n,
+                                                 int chunks_per_row, int64_t row_stride,
+                                                 const uint8_t* __restrict__ vec,
+                                                 const uint32_t* __restrict__ card_in,
+                                                 double* __restrict__ out_sim,
+                                                 uint32_t* __restrict__ out_inter,
+                                                 uint32_t* __restrict__ out_union,
+                                                 uint32_t* __restrict__ out_card) {
+    constexpr int RPI = 64 / LPR;  // rows per load instruction
+    constexpr int IT = LPR;        // iterations per tile -> 64 rows
+    const int lane = threadIdx.x & 63;
+    const int l = lane % LPR;  // chunk within the row
+    const int g = lane / LPR;  // row within the instruction
+    const bool chunk_ok = l < chunks_per_row;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    uint32_t vec_pc = 0;
+    if constexpr (HAS_VEC) {
+        if (chunk_ok) v = reinterpret_cast<const uint4*>(vec)[l];
+        vec_pc = group_sum<LPR>(popc4(v));
+    }
+    const int64_t n_tiles = (n + 63) / 64;
+    const int64_t wave_id = (int64_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+    const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x / 64);
+    for (int64_t tile = wave_id; tile < n_tiles; tile += n_waves) {
+        const int64_t base = tile * 64;
+        uint4 d[IT];
+#pragma unroll
+        for (int i = 0; i < IT; ++i) {
+            const int64_t row = base + i * RPI + g;
+            d[i] = make_uint4(0, 0, 0, 0);
+            if (chunk_ok && row < n)
+                d[i] = ld_nt16(arr + row * row_stride + (size_t)l * 16);
+        }
+        uint32_t mine = 0;  // inter | card << 16 of the row this lane ends up owning
+#pragma unroll
+        for (int i = 0; i < IT; ++i) {
+            uint32_t c = popc4(d[i]);
+            uint32_t packed = c << 16;
+            if constexpr (HAS_VEC) packed |= popc4(and4(d[i], v));
+            packed = group_sum<LPR>(packed);
+            if (l == i) mine = packed;
+        }
+        // lane (g, l) owns row base + l * RPI + g
+        const int64_t row = base + (int64_t)l * RPI + g;
+        if (row < n) {
+            uint32_t inter = mine & 0xFFFFu;
+            uint32_t card = card_in ? card_in[row] : (mine >> 16);
+            if (out_card) out_card[row] = card;
+            if constexpr (HAS_VEC) {
+                uint32_t un = card + vec_pc - inter;
+                if (out_sim) out_sim[row] = jt_from_counts(inter, un);
+                if (out_inter) out_inter[row] = inter;
+                if (out_union) out_union[row] = un;
+            }
+        }
+    }
+}
+
+// generic path: any width / alignment; one wave per row, byte-granular.
+template <bool HAS_VEC>
+__global__ __launch_bounds__(256) void k_arr_vec_generic(const uint8_t* __restrict__ arr, int64_t n,
+                                                         int64_t nbytes, int64_t row_stride,
+                                                         const uint8_t* __restrict__ vec,
+                                                         const uint32_t* __restrict__ card_in,
+                                                         double* __restrict__ out_sim,
+                                                         uint32_t* __restrict__ out_inter,
+                                                         uint32_t* __restrict__ out_union,
+                                                         uint32_t* __restrict__ out_card) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave_id = (int64_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+    const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x / 64);
+    uint32_t vpc = 0;
+    if constexpr (HAS_VEC) {
+        for (int64_t j = lane; j < nbytes; j += 64) vpc += __popc((uint32_t)vec[j]);
+        vpc = wave_sum_u32(vpc);
+    }
+    for (int64_t row = wave_id; row < n; row += n_waves) {
+        const uint8_t* r = arr + row * row_stride;
+        uint32_t c = 0, in = 0;
+        for (int64_t j = lane; j < nbytes; j += 64) {
+            uint32_t b = r[j];
+            c += __popc(b);
+            if constexpr (HAS_VEC) in += __popc(b & (uint32_t)vec[j]);
+        }
+        c = wave_sum_u32(c);
+        in = wave_sum_u32(in);
+        if (lane == 0) {
+            uint32_t card = card_in ? card_in[row] : c;
+            if (out_card) out_card[row] = card;
+            if constexpr (HAS_VEC) {
+                uint32_t un = card + vpc - in;
+                if (out_sim) out_sim[row] = jt_from_counts(in, un);
+                if (out_inter) out_inter[row] = in;
+                if (out_union) out_union[row] = un;
+            }
+        }
+    }
+}
+
+template <bool HAS_VEC>
+static int launch_arr_vec(const uint8_t* arr, int64_t n, int64_t nbytes, int64_t stride,
+                          const uint8_t* vec, const uint32_t* card, double* sim, uint32_t* inter,
+                          uint32_t* un, uint32_t* out_card, hipStream_t s) {
+    if (n == 0) return BBH_OK;
+    const bool fast = (nbytes % 16 == 0) && (stride % 16 == 0) && nbytes <= 256 &&
+                      ((uintptr_t)arr % 16 == 0) && (!HAS_VEC || (uintptr_t)vec % 16 == 0);
+    const int64_t tiles = (n + 63) / 64;
+    int64_t blocks = (tiles + 3) / 4;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    if (!fast) {
+        int64_t gb = (n + 3) / 4;
+        if (gb > 256 * 8) gb = 256 * 8;
+        hipLaunchKernelGGL((k_arr_vec_generic<HAS_VEC>), dim3((unsigned)gb), dim3(256), 0, s, arr, n,
+                           nbytes, stride, vec, card, sim, inter, un, out_card);
+        BB_HIP(hipGetLastError());
+        return BBH_OK;
+    }
+    const int cpr = (int)(nbytes / 16);
+#define BB_LAUNCH_AV(L)                                                                      \
+    hipLaunchKernelGGL((k_arr_vec<L, HAS_VEC>), dim3((unsigned)blocks), dim3(256), 0, s, arr, n, \
+                       cpr, stride, vec, card, sim, inter, un, out_card)
+    if (cpr <= 1) BB_LAUNCH_AV(1);
+    else if (cpr <= 2) BB_LAUNCH_AV(2);
+    else if (cpr <= 4) BB_LAUNCH_AV(4);
+    else if (cpr <= 8) BB_LAUNCH_AV(8);
+    else if (cpr <= 16) BB_LAUNCH_AV(16);
+    else if (cpr <= 32) BB_LAUNCH_AV(32);
+    else BB_LAUNCH_AV(64);
+#undef BB_LAUNCH_AV
+    BB_HIP(hipGetLastError());
+    return BBH_OK;
+}
+
+extern "C" int bbh_popcount_rows(const uint8_t* arr, int64_t n, int64_t nbytes, int64_t row_stride,
+                                 uint32_t* out, void* stream) {
+    BB_TRY(bb::ensure_device());
+    if (n < 0 || nbytes <= 0 || row_stride < nbytes)
+        return bb::fail(BBH_ERR_INVALID, "Input array must be 2-dimensional");
+    hipStream_t s = (hipStream_t)stream;
+    bb::DevIn a;
+    bb::DevOut o;
+    BB_TRY(a.init(arr, (size_t)(n * row_stride), s));
+    BB_TRY(o.init(out, (size_t)n * 4));
+    {
+        bb::ProfScope ps("popcount_rows", s);
+        BB_TRY(launch_arr_vec<false>((const uint8_t*)a.dev, n, nbytes, row_stride, nullptr, nullptr,
+                                     nullptr, nullptr, nullptr, (uint32_t*)o.dev, s));
+    }
+    BB_TRY(o.finish(s));
+    if (a.owned || o.needs_copy()) BB_HIP(hipStreamSynchronize(s));
+    return BBH_OK;
+}
+
+extern "C" int bbh_jt_arr_vec(const uint8_t* arr, int64_t n, int64_t nbytes, int64_t row_stride,
+                              const uint8_t* vec, const uint32_t* card, double* out_sim,
+                              uint32_t* out_inter, uint32_t* out_union, void* stream) {
+    BB_TRY(bb::ensure_device());
+    if (n < 0 || nbytes <= 0 || row_stride < nbytes || vec == nullptr)
+        return bb::fail(BBH_ERR_INVALID, "arr must be 2D, vec must be 1D");
+    hipStream_t s = (hipStream_t)stream;
+    bb::DevIn a, v, c;
+    bb::DevOut os, oi, ou;
+    BB_TRY(a.init(arr, (size_t)(n * row_stride), s));
+    BB_TRY(v.init(vec, (size_t)nbytes, s));
+    BB_TRY(c.init(card, card ? (size_t)n * 4 : 0, s));
+    BB_TRY(os.init(out_sim, (size_t)n * 8));
+    BB_TRY(oi.init(out_inter, (size_t)n * 4));
+    BB_TRY(ou.init(out_union, (size_t)n * 4));
+    {
+        bb::ProfScope ps("jt_arr_vec", s);
+        BB_TRY(launch_arr_vec<true>((const uint8_t*)a.dev, n, nbytes, row_stride,
+                                    (const uint8_t*)v.dev, (const uint32_t*)c.dev, (double*)os.dev,
+                                    (uint32_t*)oi.dev, (uint32_t*)ou.dev, nullptr, s));
+    }
+    BB_TRY(os.finish(s));
+    BB_TRY(oi.finish(s));
+    BB_TRY(ou.finish(s));
+    if (a.owned || v.owned || c.owned || os.needs_copy() || oi.needs_copy() || ou.needs_copy())
+        BB_HIP(hipStreamSynchronize(s));
+    return BBH_OK;
+}
+
+// =======================================================================================
+// K2: batched best match.  VALU(v_bcnt)-bound for nc >~ 10: every
+// lane owns one query row in registers; centroid rows are wave-uniform, so the compiler
+// fetches them through the scalar cache (s_load) and the inner loop is AND + bcnt only,
+// with no cross-lane reduction.  First-index argmax by exact integer cross-multiply.
+// =======================================================================================
+template <int W32>  // 32-bit words per row held in registers (64 for 2048 bits)
+__global__ __launch_bounds__(256) void k_best_match(const uint32_t* __restrict__ q, int64_t nq,
+                                                    const uint32_t* __restrict__ c, int nc,
+                                                    const uint32_t* __restrict__ ccard,
+                                                    int32_t* __restrict__ out_idx,
+                                                    uint32_t* __restrict__ out_inter,
+                                                    uint32_t* __restrict__ out_union,
+                                                    double* __restrict__ out_sims) {
+    const int64_t qi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool ok = qi < nq;
+    uint32_t x[W32];
+    uint32_t qc = 0;
+    const uint4* src = reinterpret_cast<const uint4*>(q + (ok ? qi : 0) * W32);
+#pragma unroll
+    for (int w = 0; w < W32 / 4; ++w) {
+        uint4 t = ok ? src[w] : make_uint4(0, 0, 0, 0);
+        x[4 * w] = t.x;
+        x[4 * w + 1] = t.y;
+        x[4 * w + 2] = t.z;
+        x[4 * w + 3] = t.w;
+        qc += popc4(t);
+    }
+    uint32_t best_i = 0, best_u = 1;
+    int best = 0;
+    for (int m = 0; m < nc; ++m) {
+        const uint32_t* cr = c + (size_t)m * W32;  // wave-uniform address
+        uint32_t inter = 0;
+#pragma unroll
+        for (int w = 0; w < W32; ++w) inter += __popc(x[w] & cr[w]);
+        uint32_t un = qc + ccard[m] - inter;
+        uint32_t unc = un < 1u ? 1u : un;
+        // inter/unc > best_i/best_u  <=>  inter*best_u > best_i*unc (exact; <= 2^26)
+        if (m == 0 || inter * best_u > best_i * unc) {
+            best_i = inter;
+            best_u = unc;
+            best = m;
+        }
+        if (out_sims && ok) out_sims[qi * nc + m] = jt_from_counts(inter, un);
+    }
+    if (ok) {
+        out_idx[qi] = best;
+        if (out_inter) out_inter[qi] = best_i;
+        // report the true (unclamped) union like the reference's denominator
+        if (out_union) out_union[qi] = (best_i == 0 && best_u == 1) ? (qc + ccard[best]) : best_u;
+    }
+}
+
+// generic width: one wave per query, lanes stride over bytes of every centroid.
+__global__ __launch_bounds__(256) void k_best_match_generic(const uint8_t* __restrict__ q, int64_t nq,
+                                                            const uint8_t* __restrict__ c, int nc,
+                                                            int64_t nbytes,
+                                                            const uint32_t* __restrict__ ccard,
+                                                            int32_t* __restrict__ out_idx,
+                                                            uint32_t* __restrict__ out_inter,
+                                                            uint32_t* __restrict__ out_union,
+                                                            double* __restrict__ out_sims) {
+    const int lane = threadIdx.x & 63;
+    const int64_t qi = (int64_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+    if (qi >= nq) return;
+    const uint8_t* qr = q + qi * nbytes;
+    uint32_t qc = 0;
+    for (int64_t j = lane; j < nbytes; j += 64) qc += __popc((uint32_t)qr[j]);
+    qc = wave_sum_u32(qc);
+    uint32_t best_i = 0, best_u = 1, best_true_u = 0;
+    int best = 0;
+    for (int m = 0; m < nc; ++m) {
+        const uint8_t* cr = c + (size_t)m * nbytes;
+        uint32_t inter = 0;
+        for (int64_t j = lane; j < nbytes; j += 64) inter += __popc((uint32_t)(qr[j] & cr[j]));
+        inter = wave_sum_u32(inter);
+        uint32_t un = qc + ccard[m] - inter;
+        uint32_t unc = un < 1u ? 1u : un;
+        if (m == 0 || inter * best_u > best_i * unc) {
+            best_i = inter;
+            best_u = unc;
+            best_true_u = un;
+            best = m;
+        }
+        if (out_sims && lane == 0) out_sims[qi * nc + m] = jt_from_counts(inter, un);
+    }
+    if (lane == 0) {
+        out_idx[qi] = best;
+        if (out_inter) out_inter[qi] = best_i;
+        if (out_union) out_union[qi] = best_true_u;
+    }
+}
+
+extern "C" int bbh_jt_best_match(const uint8_t* queries, int64_t nq, const uint8_t* cents, int64_t nc,
+                                 int64_t nbytes, int32_t* out_idx, uint32_t* out_inter,
+                                 uint32_t* out_union, double* out_sims, void* stream) {
+    BB_TRY(bb::ensure_device());
+    if (nq < 0 || nc <= 0 || nbytes <= 0 || out_idx == nullptr)
+        return bb::fail(BBH_ERR_INVALID, "best_match: need nq >= 0, nc >= 1 and an index output");
+    if (nc > (1 << 20)) return bb::fail(BBH_ERR_INVALID, "best_match: too many centroid rows");
+    hipStream_t s = (hipStream_t)stream;
+    bb::DevIn q, c;
+    bb::DevOut oi, on, ou, os;
+    BB_TRY(q.init(queries, (size_t)(nq * nbytes), s));
+    BB_TRY(c.init(cents, (size_t)(nc * nbytes), s));
+    BB_TRY(oi.init(out_idx, (size_t)nq * 4));
+    BB_TRY(on.init(out_inter, (size_t)nq * 4));
+    BB_TRY(ou.init(out_union, (size_t)nq * 4));
+    BB_TRY(os.init(out_sims, (size_t)nq * (size_t)nc * 8));
+    uint32_t* ccard = nullptr;
+    BB_HIP(hipMalloc(&ccard, (size_t)nc * 4));
+    int rc = launch_arr_vec<false>((const uint8_t*)c.dev, nc, nbytes, nbytes, nullptr, nullptr, nullptr,
+                                   nullptr, nullptr, ccard, s);
+    if (rc == BBH_OK && nq > 0) {
+        bb::ProfScope ps("jt_best_match", s);
+        const bool fast = nbytes == 256 && ((uintptr_t)q.dev % 16 == 0) && ((uintptr_t)c.dev % 16 == 0);
+        if (fast) {
+            int64_t blocks = (nq + 255) / 256;
+            hipLaunchKernelGGL((k_best_match<64>), dim3((unsigned)blocks), dim3(256), 0, s,
+                               (const uint32_t*)q.dev, nq, (const uint32_t*)c.dev, (int)nc, ccard,
+                               (int32_t*)oi.dev, (uint32_t*)on.dev, (uint32_t*)ou.dev, (double*)os.dev);
+        } else {
+            int64_t blocks = (nq + 3) / 4;
+            hipLaunchKernelGGL(k_best_match_generic, dim3((unsigned)blocks), dim3(256), 0, s,
+                               (const uint8_t*)q.dev, nq, (const uint8_t*)c.dev, (int)nc, nbytes, ccard,
+                               (int32_t*)oi.dev, (uint32_t*)on.dev, (uint32_t*)ou.dev, (double*)os.dev);
+        }
+        if (hipGetLastError() != hipSuccess) rc = bb::fail(BBH_ERR_HIP, "best_match launch failed");
+    }
+    if (rc == BBH_OK) rc = oi.finish(s);
+    if (rc == BBH_OK) rc = on.finish(s);
+    if (rc == BBH_OK) rc = ou.finish(s);
+    if (rc == BBH_OK) rc = os.finish(s);
+    hipError_t e = hipStreamSynchronize(s);
+    (void)hipFree(ccard);
+    if (rc == BBH_OK && e != hipSuccess) rc = bb::fail(BBH_ERR_HIP, "best_match: %s", hipGetErrorString(e));
+    return rc;
+}
+
+// =======================================================================================
+// unpack / add_rows / centroid_from_sum / isim_from_sum
+// =======================================================================================
+__global__ void k_unpack(const uint8_t* __restrict__ in, int64_t n, int64_t nbytes, int64_t out_bytes,
+                         uint8_t* __restrict__ out) {
+    // one thread per packed byte -> 8 output bytes, MSB first (similarity.cpp:145-155)
+    const int64_t total = n * out_bytes;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = t / out_bytes, b = t % out_bytes;
+        const uint32_t v = in[row * nbytes + b];
+        uint8_t* o = out + (row * out_bytes + b) * 8;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = (uint8_t)((v >> (7 - k)) & 1u);
+    }
+}
+
+extern "C" int bbh_unpack(const uint8_t* packed, int64_t n, int64_t nbytes, int64_t n_features,
+                          uint8_t* out, void* stream) {
+    BB_TRY(bb::ensure_device());
+    if (n_features % 8 != 0) return bb::fail(BBH_ERR_INVALID, "Only n_features divisible by 8 is supported");
+    if (n < 0 || nbytes <= 0 || n_features > nbytes * 8)
+        return bb::fail(BBH_ERR_INVALID, "Input array must be 1- or 2-dimensional");
+    hipStream_t s = (hipStream_t)stream;
+    bb::DevIn a;
+    bb::DevOut o;
+    BB_TRY(a.init(packed, (size_t)(n * nbytes), s));
+    BB_TRY(o.init(out, (size_t)(n * n_features)));
+    if (n > 0) {
+        bb::ProfScope ps("unpack", s);
+        int64_t total = n * (n_features / 8);
+        int64_t blocks = (total + 255) / 256;
+        if (blocks > 256 * 16) blocks = 256 * 16;
+        hipLaunchKernelGGL(k_unpack, dim3((unsigned)blocks), dim3(256), 0, s, (const uint8_t*)a.dev, n,
+                           nbytes, n_features / 8, (uint8_t*)o.dev);
+        BB_HIP(hipGetLastError());
+    }
+    BB_TRY(o.finish(s));
+    if (a.owned || o.needs_copy()) BB_HIP(hipStreamSynchronize(s));
+    return BBH_OK;
+}
+
+// column sums: thread per output byte-group (8 columns when packed, 1 column otherwise),
+// rows split over gridDim.y, partials combined with 64-bit atomics.
+__global__ void k_add_rows_packed(const uint8_t* __restrict__ arr, int64_t n, int64_t nbytes,
+                                  int64_t used_bytes, unsigned long long* __restrict__ out) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= used_bytes) return;
+    const int64_t rows_per = (n + gridDim.y - 1) / gridDim.y;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per;
+    const int64_t r1 = r0 + rows_per < n ? r0 + rows_per : n;
+    uint32_t acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long big[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int64_t since = 0;
+    for (int64_t r = r0; r < r1; ++r) {
+        const uint32_t v = arr[r * nbytes + b];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] += (v >> (7 - k)) & 1u;
+        if (++since == (1 << 30)) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { big[k] += acc[k]; acc[k] = 0; }
+            since = 0;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        unsigned long long t = big[k] + acc[k];
+        if (t) atomicAdd(&out[b * 8 + k], t);
+    }
+}
+
+__global__ void k_add_rows_u8(const uint8_t* __restrict__ arr, int64_t n, int64_t ncols,
+                              unsigned long long* __restrict__ out) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncols) return;
+    const int64_t rows_per = (n + gridDim.y - 1) / gridDim.y;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per;
+    const int64_t r1 = r0 + rows_per < n ? r0 + rows_per : n;
+    unsigned long long acc = 0;
+    for (int64_t r = r0; r < r1; ++r) acc += arr[r * ncols + c];
+    if (acc) atomicAdd(&out[c], acc);
+}
+
+static int add_rows_dev(const uint8_t* arr, int64_t n, int64_t n_cols, int packed, int64_t n_features,
+                        unsigned long long* out_dev, hipStream_t s) {
+    BB_HIP(hipMemsetAsync(out_dev, 0, (size_t)n_features * 8, s));
+    if (n == 0) return BBH_OK;
+    int64_t splits = n / 256;
+    if (splits < 1) splits = 1;
+    if (splits > 1024) splits = 1024;
+    bb::ProfScope ps("add_rows", s);
+    if (packed) {
+        int64_t used = n_features / 8;
+        hipLaunchKernelGGL(k_add_rows_packed, dim3((unsigned)((used + 63) / 64), (unsigned)splits),
+                           dim3(64), 0, s, arr, n, n_cols, used, out_dev);
+    } else {
+        hipLaunchKernelGGL(k_add_rows_u8, dim3((unsigned)((n_cols + 63) / 64), (unsigned)splits), dim3(64),
+                           0, s, arr, n, n_cols, out_dev);
+    }
+    BB_HIP(hipGetLastError());
+    return BBH_OK;
+}
+
+extern "C" int bbh_add_rows(const uint8_t* arr, int64_t n, int64_t n_cols, int packed,
+                            int64_t n_features, uint64_t* out, void* stream) {
+    BB_TRY(bb::ensure_device());
+    if (n < 0 || n_cols <= 0) return bb::fail(BBH_ERR_INVALID, "Input array must be 2-dimensional");
+    if (packed && (n_features % 8 != 0 || n_features > n_cols * 8))
+        return bb::fail(BBH_ERR_INVALID, "Only n_features divisible by 8 is supported");
+    if (!packed && n_features != n_cols) return bb::fail(BBH_ERR_INVALID, "n_features must equal the column count");
+    hipStream_t s = (hipStream_t)stream;
+    bb::DevIn a;
+    bb::DevOut o;
+    BB_TRY(a.init(arr, (size_t)(n * n_cols), s));
+    BB_TRY(o.init(out, (size_t)n_features * 8));
+    BB_TRY(add_rows_dev((const uint8_t*)a.dev, n, n_cols, packed, n_features, (unsigned long long*)o.dev, s));
+    BB_TRY(o.finish(s));
+    if (a.owned || o.needs_copy()) BB_HIP(hipStreamSynchronize(s));
+    return BBH_OK;
+}
+
+__device__ __forceinline__ unsigned long long load_ls(const void* p, int width, int64_t j) {
+    switch (width) {
+        case 1: return ((const uint8_t*)p)[j];
+        case 2: return ((const uint16_t*)p)[j];
+        case 4: return ((const uint32_t*)p)[j];
+        default: return ((const unsigned long long*)p)[j];
+    }
+}
+
+// one thread per output byte (pack) or per feature (no pack)
+__global__ void k_centroid_from_sum(const void* __restrict__ ls, int width, int64_t nf, int64_t n_samples,
+                                    int pack, uint8_t* __restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (!pack) {
+        if (t >= nf) return;
+        unsigned long long v = load_ls(ls, width, t);
+        out[t] = n_samples <= 1 ? (uint8_t)v : (uint8_t)((double)v >= (double)n_samples * 0.5);
+        return;
+    }
+    const int64_t nb = (nf + 7) / 8;
+    if (t >= nb) return;
+    uint32_t byte = 0;
+    for (int k = 0; k < 8; ++k) {
+        const int64_t j = t * 8 + k;
+        if (j >= nf) break;
+        unsigned long long v = load_ls(ls, width, j);
+        // n<=1: cast to uint8, packbits treats non-zero as 1 (_py_similarity.py:36-41)
+        bool bit = n_samples <= 1 ? ((uint8_t)v != 0) : ((double)v >= (double)n_samples * 0.5);
+        if (bit) byte |= 0x80u >> k;
+    }
+    out[t] = (uint8_t)byte;
+}
+
+extern "C" int bbh_centroid_from_sum(const void* linear_sum, int32_t ls_width, int64_t n_features,
+                                     int64_t n_samples, int pack, uint8_t* out, void* stream) {
+    BB_TRY(bb::ensure_device());
+    if (n_features <= 0 || (ls_width != 1 && ls_width != 2 && ls_width != 4 && ls_width != 8))
+        return bb::fail(BBH_ERR_INVALID, "linear_sum must be 1-dimensional");
+    hipStream_t s = (hipStream_t)stream;
+    bb::DevIn a;
+    bb::DevOut o;
+    const int64_t out_n = pack ? (n_features + 7) / 8 : n_features;
+    BB_TRY(a.init(linear_sum, (size_t)(n_features * ls_width), s));
+    BB_TRY(o.init(out, (size_t)out_n));
+    {
+        bb::ProfScope ps("centroid_from_sum", s);
+        hipLaunchKernelGGL(k_centroid_from_sum, dim3((unsigned)((out_n + 255) / 256)), dim3(256), 0, s, a.dev,
+                           (int)ls_width, n_features, n_samples, pack, (uint8_t*)o.dev);
+        BB_HIP(hipGetLastError());
+    }
+    BB_TRY(o.finish(s));
+    if (a.owned || o.needs_copy()) BB_HIP(hipStreamSynchronize(s));
+    return BBH_OK;
+}
+
+// exact u64 moments (wrap-around mod 2^64 like the reference's uint64 accumulators),
+// then the f64 formula; single block.
+__global__ __launch_bounds__(256) void k_isim_from_sum(const void* __restrict__ ls, int width, int64_t nf,
+                                                       long long n_objects, double* __restrict__ out) {
+    __shared__ unsigned long long r1[4], r2[4];
+    unsigned long long s1 = 0, s2 = 0;
+    for (int64_t j = threadIdx.x; j < nf; j += blockDim.x) {
+        unsigned long long v = load_ls(ls, width, j);
+        s1 += v;
+        s2 += v * v;
+    }
+    s1 = wave_sum_u64(s1);
+    s2 = wave_sum_u64(s2);
+    if ((threadIdx.x & 63) == 0) {
+        r1[threadIdx.x >> 6] = s1;
+        r2[threadIdx.x >> 6] = s2;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long a = r1[0] + r1[1] + r1[2] + r1[3];
+        unsigned long long b = r2[0] + r2[1] + r2[2] + r2[3];
+        *out = isim_from_moments(a, b, (unsigned long long)n_objects);
+    }
+}
+
+static int isim_dev(const void* ls_dev, int width, int64_t nf, int64_t n_objects, double* out_host,
+                    int* warn, hipStream_t s) {
+    if (warn) *warn = 0;
+    if (n_objects < 2) {  // similarity.cpp:275-279
+        if (warn) *warn = 1;
+        *out_host = NAN;
+        return BBH_OK;
+    }
+    double* d = nullptr;
+    BB_HIP(hipMalloc(&d, 8));
+    {
+        bb::ProfScope ps("isim_from_sum", s);
+        hipLaunchKernelGGL(k_isim_from_sum, dim3(1), dim3(256), 0, s, ls_dev, width, nf, (long long)n_objects, d);
+    }
+    hipError_t e = hipMemcpyAsync(out_host, d, 8, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(d);
+    if (e != hipSuccess) return bb::fail(BBH_ERR_HIP, "isim_from_sum: %s", hipGetErrorString(e));
+    return BBH_OK;
+}
+
+extern "C" int bbh_isim_from_sum(const void* linear_sum, int32_t ls_width, int64_t n_features,
+                                 int64_t n_objects, double* out, int* warn, void* stream) {
+    BB_TRY(bb::ensure_device());
+    if (out == nullptr || n_features <= 0 ||
+        (ls_width != 1 && ls_width != 2 && ls_width != 4 && ls_width != 8))
+        return bb::fail(BBH_ERR_INVALID, "linear_sum must be a 1D array");
+    hipStream_t s = (hipStream_t)stream;
+    bb::DevIn a;
+    BB_TRY(a.init(linear_sum, (size_t)(n_features * ls_width), s));
+    return isim_dev(a.dev, ls_width, n_features, n_objects, out, warn, s);
+}
+
+extern "C" int bbh_isim_rows(const uint8_t* arr, int64_t n, int64_t n_cols, int packed,
+                             int64_t n_features, double* out, int* warn, void* stream) {
+    BB_TRY(bb::ensure_device());
+    if (out == nullptr || n < 0 || n_cols <= 0) return bb::fail(BBH_ERR_INVALID, "Input array must be 2-dimensional");
+    if (packed && (n_features % 8 != 0 || n_features > n_cols * 8))
+        return bb::fail(BBH_ERR_INVALID, "Only n_features divisible by 8 is supported");
+    hipStream_t s = (hipStream_t)stream;
+    bb::DevIn a;
+    BB_TRY(a.init(arr, (size_t)(n * n_cols), s));
+    unsigned long long* ls = nullptr;
+    BB_HIP(hipMalloc(&ls, (size_t)n_features * 8));
+    int rc = add_rows_dev((const uint8_t*)a.dev, n, n_cols, packed, n_features, ls, s);
+    if (rc == BBH_OK) rc = isim_dev(ls, 8, n_features, n, out, warn, s);
+    (void)hipStreamSynchronize(s);
+    (void)hipFree(ls);
+    return rc;
+}
+
+// =======================================================================================
+// jt_most_dissimilar_packed (similarity.cpp:413-471) composed from the kernels above.
+// The tree engine has its own fused in-kernel version (bb_tree.hip, split_node).
+// =======================================================================================
+static int64_t host_first_argmin(const double* v, int64_t n) {
+    int64_t b = 0;
+    for (int64_t i = 1; i < n; ++i)
+        if (v[i] < v[b]) b = i;  // std::min_element: first minimum
+    return b;
+}
+
+extern "C" int bbh_most_dissimilar(const uint8_t* Y, int64_t n, int64_t nbytes, int64_t n_features,
+                                   int64_t* idx1, int64_t* idx2, double* sims1, double* sims2,
+                                   void* stream) {
+    BB_TRY(bb::ensure_device());
+    if (n <= 0 || nbytes <= 0 || idx1 == nullptr || idx2 == nullptr)
+        return bb::fail(BBH_ERR_INVALID, "Input array must be 2-dimensional");
+    if (n_features % 8 != 0 || n_features > nbytes * 8)
+        return bb::fail(BBH_ERR_INVALID, "Only features divisible by 8 is supported");
+    hipStream_t s = (hipStream_t)stream;
+    bb::DevIn y;
+    bb::DevOut o1, o2;
+    BB_TRY(y.init(Y, (size_t)(n * nbytes), s));
+    BB_TRY(o1.init(sims1, (size_t)n * 8));
+    BB_TRY(o2.init(sims2, (size_t)n * 8));
+    const uint8_t* yd = (const uint8_t*)y.dev;
+    void* scratch = nullptr;
+    const size_t sz_ls = (size_t)nbytes * 8 * 8, sz_card = (size_t)n * 4, sz_sim = (size_t)n * 8;
+    const size_t off_cen = sz_ls, off_card = off_cen + ((nbytes + 15) / 16) * 16;
+    const size_t off_sim = (off_card + sz_card + 15) / 16 * 16;
+    BB_HIP(hipMalloc(&scratch, off_sim + 2 * sz_sim));
+    auto* ls = (unsigned long long*)scratch;
+    auto* cen = (uint8_t*)scratch + off_cen;
+    auto* card = (uint32_t*)((uint8_t*)scratch + off_card);
+    auto* simc = (double*)((uint8_t*)scratch + off_sim);
+    auto* sim_tmp = simc + n;
+    std::vector<double> h((size_t)n);
+    int rc = BBH_OK;
+    auto run = [&]() -> int {
+        BB_HIP(hipMemsetAsync(cen, 0, (size_t)nbytes, s));
+        BB_TRY(add_rows_dev(yd, n, nbytes, 1, n_features, ls, s));
+        hipLaunchKernelGGL(k_centroid_from_sum, dim3((unsigned)((n_features / 8 + 255) / 256)), dim3(256), 0, s,
+                           (const void*)ls, 8, n_features, n, 1, cen);
+        BB_TRY(launch_arr_vec<false>(yd, n, nbytes, nbytes, nullptr, nullptr, nullptr, nullptr, nullptr, card, s));
+        BB_TRY(launch_arr_vec<true>(yd, n, nbytes, nbytes, cen, card, simc, nullptr, nullptr, nullptr, s));
+        BB_HIP(hipMemcpyAsync(h.data(), simc, sz_sim, hipMemcpyDeviceToHost, s));
+        BB_HIP(hipStreamSynchronize(s));
+        const int64_t f1 = host_first_argmin(h.data(), n);
+        double* d1 = o1.dev ? (double*)o1.dev : sim_tmp;
+        BB_TRY(launch_arr_vec<true>(yd, n, nbytes, nbytes, yd + f1 * nbytes, card, d1, nullptr, nullptr, nullptr, s));
+        BB_HIP(hipMemcpyAsync(h.data(), d1, sz_sim, hipMemcpyDeviceToHost, s));
+        BB_HIP(hipStreamSynchronize(s));
+        const int64_t f2 = host_first_argmin(h.data(), n);
+        if (o2.dev)
+            BB_TRY(launch_arr_vec<true>(yd, n, nbytes, nbytes, yd + f2 * nbytes, card, (double*)o2.dev, nullptr,
+                                        nullptr, nullptr, s));
+        *idx1 = f1;
+        *idx2 = f2;
+        return BBH_OK;
+    };
+    {
+        bb::ProfScope ps("most_dissimilar", s);
+        rc = run();
+    }
+    if (rc == BBH_OK) rc = o1.finish(s);
+    if (rc == BBH_OK) rc = o2.finish(s);
+    hipError_t e = hipStreamSynchronize(s);
+    (void)hipFree(scratch);
+    if (rc == BBH_OK && e != hipSuccess) rc = bb::fail(BBH_ERR_HIP, "most_dissimilar: %s", hipGetErrorString(e));
+    return rc;
+}
+
+// =======================================================================================
+// misc C ABI
+// =======================================================================================
+extern "C" const char* bbh_last_error(void) { return bb::g_err; }
+
+extern "C" int bbh_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+extern "C" int bbh_device_info(int device, char* buf, size_t buflen) {
+    hipDeviceProp_t p;
+    BB_HIP(hipGetDeviceProperties(&p, device));
+    snprintf(buf, buflen, "%s %s CUs=%d HBM=%.1fGiB clock=%dMHz", p.gcnArchName, p.name,
+             p.multiProcessorCount, (double)p.totalGlobalMem / (1024.0 * 1024.0 * 1024.0), p.clockRate / 1000);
+    return BBH_OK;
+}
+
+extern "C" int bbh_profile_enable(int on) {
+    bb::g_prof_on = on != 0;
+    return BBH_OK;
+}
+
+extern "C" int bbh_profile_reset(void) {
+    std::lock_guard<std::mutex> lk(bb::g_prof_mu);
+    for (auto& r : bb::g_prof) {
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+    }
+    bb::g_prof.clear();
+    return BBH_OK;
+}
+
+extern "C" int bbh_profile_get(const char* name, int64_t* launches, double* total_ms) {
+    std::lock_guard<std::mutex> lk(bb::g_prof_mu);
+    int64_t cnt = 0;
+    double ms = 0.0;
+    for (auto& r : bb::g_prof) {
+        if (r.name != name) continue;
+        if (hipEventSynchronize(r.b) != hipSuccess) continue;
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) {
+            ms += t;
+            cnt++;
+        }
+    }
+    if (launches) *launches = cnt;
+    if (total_ms) *total_ms = ms;
+    return BBH_OK;
+}

@@ -1,0 +1,162 @@
+r"""GPU parity of the stateless HIP kernels (through the C ABI) against the CPU oracle and
+the reference-generated fixtures.  Integers bit-exact; float64 bit-exact (stronger than
+the 1e-6 the north star asks for)."""
+from __future__ import annotations
+
+import ctypes as C
+import warnings
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from oracle_engine import oracle_lib
+
+pytestmark = pytest.mark.gpu
+
+GOLD = Path(__file__).resolve().parent / "golden"
+SHAPES = [(10, 256), (1, 256), (7, 128), (51, 256), (255, 256), (33, 253), (64, 4), (5, 64)]
+
+
+@pytest.fixture(scope="module")
+def SIM():
+    return dict(np.load(GOLD / "similarity.npz"))
+
+
+def o_sims(arr, vec):
+    lib = oracle_lib()
+    n, nb = arr.shape
+    s, i, u = np.empty(n), np.empty(n, np.uint32), np.empty(n, np.uint32)
+    lib.bbo_jt_arr_vec(arr.ctypes.data, n, nb, vec.ctypes.data, None, s.ctypes.data, i.ctypes.data, u.ctypes.data)
+    return s, i, u
+
+
+@pytest.mark.parametrize("k", range(len(SHAPES)))
+def test_kernels_vs_reference_fixtures(SIM, k):
+    import bblean_amd.similarity as S
+
+    pre = f"s{k}_"
+    arr, vec = SIM[pre + "arr"], SIM[pre + "vec"]
+    n, nb = arr.shape
+    assert (S._popcount_2d(arr) == SIM[pre + "popcount_cpp"]).all()
+    assert (S._jt_sim_arr_vec_packed(arr, vec) == SIM[pre + "sims_cpp"]).all()
+    assert (S._jt_sim_arr_vec_packed(arr, np.zeros(nb, np.uint8)) == SIM[pre + "sims_zero_cpp"]).all()
+    i1, i2, s1, s2 = S.jt_most_dissimilar_packed(arr)
+    assert [i1, i2] == SIM[pre + "md_idx"].tolist()
+    assert (s1 == SIM[pre + "md_s1"]).all() and (s2 == SIM[pre + "md_s2"]).all()
+    un = S._unpack_fingerprints_hip(arr)
+    assert (un == np.unpackbits(arr, axis=-1)).all()
+    ls = S._add_rows(un)
+    assert (ls == SIM[pre + "add_rows"]).all()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        isim = S.jt_isim_from_sum(ls, n)
+        isim_p = S.jt_isim_packed(arr)
+    exp = SIM[pre + "isim_cpp"][0]
+    assert (np.isnan(isim) and np.isnan(exp)) or isim == exp
+    expp = SIM[pre + "isim_packed_cpp"][0]
+    assert (np.isnan(isim_p) and np.isnan(expp)) or isim_p == expp
+    for dt in (np.uint64, np.uint32, np.uint16):
+        assert (S.centroid_from_sum(ls.astype(dt), n) == SIM[pre + "centroid_py"]).all()
+    assert (S.centroid_from_sum(ls, n, pack=False) == SIM[pre + "centroid_unpacked_py"]).all()
+    if n >= 2:
+        assert S.jt_isim_radius_compl_from_sum(ls, n) == SIM[pre + "radius_compl"][0]
+
+
+def test_reference_known_answers(SIM):
+    import bblean_amd.similarity as S
+    from bblean_amd import make_fake_fingerprints
+
+    fps = make_fake_fingerprints(10, seed=17408390758220920002)
+    assert S._popcount_2d(fps).tolist() == [1137, 124, 558, 1159, 281, 323, 1264, 1252, 879, 631]
+    assert S._popcount_1d(fps[0]) == 1137
+    out = S.jt_sim_packed(fps, fps[0])
+    assert (out == SIM["ka_sims_first"]).all()
+    assert (S.jt_sim_packed(fps[0], fps) == out).all()
+    assert S.jt_sim_packed(fps[0], fps[0]) == 1.0
+    i1, i2, s1, s2 = S.jt_most_dissimilar_packed(fps)
+    assert (i1, i2) == (1, 2)
+    un = make_fake_fingerprints(100, seed=17408390758220920002, pack=False)
+    assert S.jt_isim_from_sum(un.sum(0), 100) == 0.21824334501491158
+    assert S.jt_isim(un, input_is_packed=False) == 0.21824334501491158
+    assert S.jt_isim(np.packbits(un, axis=1)) == 0.21824334501491158
+    with pytest.warns(RuntimeWarning):
+        assert np.isnan(S.jt_isim_from_sum(un[:1].sum(0), 1))
+    assert S.jt_isim_from_sum(np.zeros(2048, np.uint64), 100) == 1.0
+    un10 = make_fake_fingerprints(10, seed=17408390758220920002, pack=False)
+    assert (S.jt_compl_isim(un10, input_is_packed=False) == SIM["ka_compl_isim10"]).all()
+    assert (S._unpack_fingerprints_hip(SIM["ka_fps2024"]) == SIM["ka_unpack2024"]).all()
+    with pytest.raises(RuntimeError):
+        S._jt_sim_arr_vec_packed(fps, fps)  # vec must be 1D
+    with pytest.raises(RuntimeError):
+        S._jt_sim_arr_vec_packed(fps, fps[0][:100])
+
+
+@pytest.mark.parametrize("n,nb", [(1, 256), (63, 256), (64, 256), (65, 256), (4097, 256), (1000, 128),
+                                  (1000, 64), (777, 16), (300, 512), (129, 1024), (500, 253), (500, 100)])
+def test_arr_vec_random_vs_oracle(n, nb):
+    import bblean_amd.similarity as S
+
+    rng = np.random.default_rng(n * 1000 + nb)
+    arr = rng.integers(0, 256, (n, nb), dtype=np.uint8)
+    arr[rng.integers(0, n, max(n // 10, 1))] = 0
+    arr[::7] &= rng.integers(0, 256, (len(arr[::7]), nb), dtype=np.uint8)
+    vec = arr[rng.integers(0, n)].copy()
+    s, i, u = o_sims(arr, vec)
+    assert (S._jt_sim_arr_vec_packed(arr, vec) == s).all()
+    gi, gu = S._jt_counts_arr_vec_packed(arr, vec)
+    assert (gi == i).all() and (gu == u).all()
+    pc = np.empty(n, np.uint32)
+    oracle_lib().bbo_popcount_rows(arr.ctypes.data, n, nb, pc.ctypes.data)
+    assert (S._popcount_2d(arr) == pc).all()
+
+
+def test_arr_vec_device_resident_large():
+    r"""1M x 2048-bit rows already in HBM (BASELINE.json config[1] size): popcount identity
+    sim(x, x) == 1, symmetry on a sample, and a checksum against the oracle on a slice."""
+    import torch
+
+    import bblean_amd.similarity as S
+
+    g = torch.Generator(device="cuda").manual_seed(5)
+    arr = torch.randint(0, 256, (1_000_000, 256), dtype=torch.uint8, device="cuda", generator=g)
+    arr &= torch.randint(0, 256, (1_000_000, 256), dtype=torch.uint8, device="cuda", generator=g)
+    vec = arr[12345].clone()
+    sims = S._jt_sim_arr_vec_packed(arr, vec)
+    torch.cuda.synchronize()
+    assert sims[12345].item() == 1.0
+    host = arr[:5000].cpu().numpy()
+    s, _, _ = o_sims(host, vec.cpu().numpy())
+    assert (sims[:5000].cpu().numpy() == s).all()
+    assert float(sims.max()) <= 1.0 and float(sims.min()) >= 0.0
+
+
+@pytest.mark.parametrize("nq,nc,nb", [(1, 1, 256), (100, 51, 256), (1000, 255, 256), (257, 13, 128), (64, 7, 253)])
+def test_best_match_vs_oracle(nq, nc, nb):
+    import bblean_amd.similarity as S
+
+    rng = np.random.default_rng(nq + nc + nb)
+    q = rng.integers(0, 256, (nq, nb), dtype=np.uint8) & rng.integers(0, 256, (nq, nb), dtype=np.uint8)
+    c = rng.integers(0, 256, (nc, nb), dtype=np.uint8) & rng.integers(0, 256, (nc, nb), dtype=np.uint8)
+    if nc > 3:
+        c[2] = c[1]  # tie -> first index must win
+    if nq > 2:
+        q[1] = 0
+    idx, inter, union, sims = S.jt_best_match_packed(q, c, return_sims=True)
+    for i in range(nq):
+        s, ii, uu = o_sims(c, q[i])
+        assert (sims[i] == s).all()
+        j = int(np.argmax(s))
+        assert idx[i] == j and inter[i] == ii[j] and union[i] == uu[j]
+
+
+def test_sim_matrix_matches_rowwise():
+    import bblean_amd.similarity as S
+    from bblean_amd import make_fake_fingerprints
+
+    fps = make_fake_fingerprints(60, seed=3)
+    m = S.jt_sim_matrix_packed(fps)
+    for i in range(60):
+        row = S.jt_sim_packed(fps, fps[i])
+        row[i] = 1.0
+        assert (m[i] == row).all()

@@ -1,0 +1,93 @@
+r"""GPU parity of the HBM-resident tree engine: every reference-generated end-to-end
+fixture (tests/golden/trees.npz) and larger seeded runs against the CPU oracle.  Cluster
+ids, member order, centroids and BitFeature tables must be identical."""
+from __future__ import annotations
+
+import numpy as np
+import pytest
+
+from cases import TREE_CASES, sparse_ecfp_like
+from oracle_engine import OracleEngine
+from tree_cases import run_case
+
+from bblean_amd import BitBirch, make_fake_fingerprints
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("case", TREE_CASES, ids=[c["name"] for c in TREE_CASES])
+def test_hip_tree_vs_reference_fixture(case):
+    run_case(case, None)  # None -> the product's HIP engine
+
+
+def _same(a: BitBirch, b: BitBirch) -> None:
+    assert a.get_cluster_mol_ids() == b.get_cluster_mol_ids()
+    assert (a.get_assignments() == b.get_assignments()).all()
+    assert (np.array(a.get_centroids()) == np.array(b.get_centroids())).all()
+    ba, ma = a._bf_to_np()
+    bo, mo = b._bf_to_np()
+    assert list(ba) == list(bo)
+    for k in ba:
+        assert (np.array(ba[k]) == np.array(bo[k])).all() and ma[k] == mo[k]
+
+
+@pytest.mark.parametrize("crit,thr,bf,n,kind", [
+    ("diameter", 0.3, 50, 100_000, "fake"),
+    ("diameter", 0.3, 254, 40_000, "fake"),
+    ("tolerance-diameter", 0.3, 50, 30_000, "fake"),
+    ("diameter", 0.65, 50, 30_000, "fake"),
+    ("radius", 0.5, 50, 10_000, "fake"),
+    ("tolerance-radius", 0.4, 50, 10_000, "fake"),
+    ("tolerance-legacy", 0.5, 50, 10_000, "fake"),
+    ("diameter", 0.3, 50, 50_000, "sparse"),
+    ("diameter", 0.6, 50, 20_000, "sparse"),
+])
+def test_hip_tree_vs_oracle_large(crit, thr, bf, n, kind):
+    if kind == "fake":
+        fps = np.concatenate([make_fake_fingerprints(min(10_000, n), seed=500 + i) for i in range((n + 9999) // 10_000)])[:n]
+    else:
+        fps = sparse_ecfp_like(n, 2048, 99)
+    hip = BitBirch(branching_factor=bf, threshold=thr, merge_criterion=crit).fit(fps)
+    ora = BitBirch(branching_factor=bf, threshold=thr, merge_criterion=crit, _engine_factory=OracleEngine).fit(fps)
+    _same(hip, ora)
+    s_h, s_o = hip._engine.stats(), ora._engine.stats()
+    assert s_h[:7].tolist() == s_o[:7].tolist()  # same comparisons, merges, appends, splits
+
+
+def test_hip_refine_pipeline_vs_oracle():
+    r"""config[2] shape at test scale: fit, then refine with tolerance-diameter."""
+    fps = np.concatenate([make_fake_fingerprints(10_000, seed=900 + i) for i in range(3)])
+    trees = []
+    for fac in (None, OracleEngine):
+        t = BitBirch(branching_factor=50, threshold=0.3, merge_criterion="diameter", _engine_factory=fac).fit(fps)
+        t.set_merge("tolerance-diameter", tolerance=0.05)
+        t.refine_inplace(fps, n_largest=1)
+        trees.append(t)
+    _same(*trees)
+
+
+def test_hip_device_resident_input():
+    import torch
+
+    fps = make_fake_fingerprints(5000, seed=4242)
+    dev = torch.from_numpy(fps).cuda()
+    a = BitBirch(branching_factor=50, threshold=0.3).fit(dev)
+    b = BitBirch(branching_factor=50, threshold=0.3).fit(fps)
+    assert a.get_cluster_mol_ids() == b.get_cluster_mol_ids()
+
+
+def test_hip_edge_cases():
+    with pytest.raises(ValueError):
+        BitBirch().fit(np.zeros((0, 256), dtype=np.uint8), n_features=2048)
+    for rep in (1, 2, 10):
+        z = np.zeros((rep, 256), dtype=np.uint8)
+        assert BitBirch().fit(z, n_features=2048).get_cluster_mol_ids() == [list(range(rep))]
+        o = np.full((rep, 256), 255, dtype=np.uint8)
+        assert BitBirch().fit(o, n_features=2048).get_cluster_mol_ids() == [list(range(rep))]
+    t = BitBirch(branching_factor=50, threshold=0.3).fit(make_fake_fingerprints(3000, seed=1))
+    t.delete_internal_nodes()
+    with pytest.raises(ValueError):
+        t.fit(make_fake_fingerprints(10, seed=2))
+    t.reset()
+    t.fit(make_fake_fingerprints(10, seed=2))
+    assert t.num_fitted_fps == 10
