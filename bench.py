@@ -1,0 +1,230 @@
+#!/usr/bin/env python3
+r"""Benchmark of the BitBIRCH insertion hot path on MI355X.
+
+One "step" = one pass of the hot path over one batch: `BitBirch.fit` of the whole
+synthetic workload (BASELINE.json configs[1]: 1 M synthetic 2048-bit packed fingerprints,
+threshold 0.3, branching factor 50, diameter merge) into a fresh HBM-resident tree, with
+the fingerprints already resident in HBM when the timed region starts.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--n-fps M]
+
+For N > 1 (launched by torch.distributed.run, one rank per GPU) every rank clusters its own
+shard of the same size - the data-parallel first round of the reference's multiround scheme
+(multiround.py:401-422) - with no collective inside the timed region (weak scaling).
+
+Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (the tree insertion
+kernel; algorithmic bytes = 264 B per clustered fingerprint) timed
+with HIP events on its launch stream inside libbbhip; `k1_roofline` is the arr-vec Tanimoto
+kernel (264 B per row) that the north star's HBM target refers to.  `cpu_baseline` is the
+CPU oracle (a C restatement of the reference path, kind "port") on a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+REPO = Path(__file__).resolve().parent
+sys.path.insert(0, str(REPO))
+sys.path.insert(0, str(REPO / "tests"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+BYTES_PER_FP = 264  # 256 B row read once + 8 B label
+
+
+def synth_fake_fps(n: int, seed: int, device):
+    r"""S-fake(N, seed): same distribution as the reference's make_fake_fingerprints
+    (fingerprints.py:70-108: popcount ~ rint(truncnorm(750, 400)) in [1, 2047], uniformly
+    random bit positions), generated on the GPU in chunks.  Returns packed uint8 [n, 256]."""
+    import torch
+
+    g = torch.Generator(device=device).manual_seed(seed)
+    out = torch.empty((n, 256), dtype=torch.uint8, device=device)
+    weights = torch.tensor([128, 64, 32, 16, 8, 4, 2, 1], dtype=torch.int32, device=device)
+    chunk = 50_000
+    for lo in range(0, n, chunk):
+        m = min(chunk, n - lo)
+        pops = torch.empty(m, device=device)
+        todo = torch.ones(m, dtype=torch.bool, device=device)
+        while bool(todo.any()):
+            draw = torch.randn(m, device=device, generator=g) * 400.0 + 750.0
+            ok = (draw >= 1.0) & (draw <= 2047.0)
+            take = todo & ok
+            pops[take] = draw[take]
+            todo &= ~ok
+        pops = torch.round(pops).to(torch.int64)
+        scores = torch.rand((m, 2048), device=device, generator=g)
+        ranks = scores.argsort(dim=1).argsort(dim=1)
+        bits = (ranks < pops[:, None]).to(torch.int32)
+        out[lo : lo + m] = (bits.view(m, 256, 8) * weights).sum(dim=2).to(torch.uint8)
+    return out
+
+
+def cpu_baseline(fps_host, bf: int, thr: float, sample: int) -> dict:
+    from oracle_engine import OracleEngine
+
+    import numpy as np
+
+    eng = OracleEngine(bf, thr, 0, 0.0, np.zeros(0), 2048)
+    t0 = time.perf_counter()
+    eng.fit_packed(fps_host[:sample])
+    dt = time.perf_counter() - t0
+    eng.close()
+    return {
+        "value": sample / dt,
+        "unit": "fingerprints/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"oracle (C restatement of the reference path) fit of the first {sample} "
+                  f"fingerprints of the same workload, {dt:.1f} s on one host core",
+    }
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n-fps", type=int, default=1_000_000)
+    ap.add_argument("--bf", type=int, default=50)
+    ap.add_argument("--threshold", type=float, default=0.3)
+    ap.add_argument("--cpu-sample", type=int, default=300_000)
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist  # type: ignore[no-redef]
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from bblean_amd import BitBirch, _lib
+
+    lib = _lib.load()
+    n = args.n_fps
+    fps = synth_fake_fps(n, seed=1000 + rank, device=dev)  # resident in HBM
+    torch.cuda.synchronize()
+
+    def one_step() -> BitBirch:
+        tree = BitBirch(branching_factor=args.bf, threshold=args.threshold, merge_criterion="diameter",
+                        device=local_rank)
+        tree.fit(fps)
+        return tree
+
+    def barrier() -> None:
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step()
+    lib.bbh_profile_enable(1)
+    lib.bbh_profile_reset()
+    barrier()
+    t0 = time.perf_counter()
+    tree = None
+    for _ in range(args.steps):
+        tree = one_step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    launches, total_ms = C.c_int64(0), C.c_double(0.0)
+    lib.bbh_profile_get(b"tree_insert", C.byref(launches), C.byref(total_ms))
+    lib.bbh_profile_enable(0)
+    k_launches = max(int(launches.value), 1)
+    avg_ms = total_ms.value / k_launches
+    fps_per_launch = args.steps * n / k_launches
+    achieved = BYTES_PER_FP * fps_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+
+    # K1 (arr-vec Tanimoto) on the same resident array: the HBM-bound kernel
+    from bblean_amd.similarity import _jt_sim_arr_vec_packed
+
+    vec = fps[0].clone()
+    for _ in range(3):
+        _jt_sim_arr_vec_packed(fps, vec)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 20
+    e0.record()
+    for _ in range(reps):
+        _jt_sim_arr_vec_packed(fps, vec)
+    e1.record()
+    torch.cuda.synchronize()
+    k1_ms = e0.elapsed_time(e1) / reps
+    k1_gbs = BYTES_PER_FP * n / (k1_ms * 1e-3) / 1e9
+
+    if rank == 0:
+        n_clusters = len(tree._leaves()["ids"]) if tree is not None else 0
+        out = {
+            "metric": "fingerprints/sec clustered (2048-bit, thr=0.3)",
+            "value": world * args.steps * n / elapsed,
+            "unit": "fingerprints/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{n} synthetic 2048-bit packed fingerprints per GPU (make_fake_fingerprints "
+                            f"popcount distribution), threshold={args.threshold}, branching_factor={args.bf}, "
+                            "merge=diameter, BitBirch.fit into a fresh HBM-resident tree, inputs resident in HBM",
+                "clusters": n_clusters,
+                "multi_gpu": "independent shard per GPU (multiround round 1), no collective in the timed region",
+            },
+            "roofline": {
+                "kernel": "k_tree_insert",
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "launches": k_launches,
+                "avg_launch_ms": avg_ms,
+                "note": "latency/dependency-bound sequential insertion; 264 algorithmic bytes per fingerprint",
+            },
+            "k1_roofline": {
+                "kernel": "k_arr_vec<16,true> (arr-vec Tanimoto, 264 B/row)",
+                "bound": "hbm",
+                "achieved": k1_gbs,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": k1_gbs / HBM_PEAK_GBS,
+                "rows": n,
+                "avg_launch_ms": k1_ms,
+            },
+        }
+        if not args.no_cpu and world == 1:
+            sample = min(args.cpu_sample, n)
+            out["cpu_baseline"] = cpu_baseline(fps[:sample].cpu().numpy(), args.bf, args.threshold, sample)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
