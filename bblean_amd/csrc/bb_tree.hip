@@ -7,23 +7,29 @@
 // _jt_sim_arr_vec_packed + np.argmax (similarity.cpp:374, bitbirch.py:317-320) and
 // _split_node + jt_most_dissimilar_packed (bitbirch.py:162-211, similarity.cpp:413-471).
 //
-// Data layout in HBM (all pools are flat arrays indexed by id, grown by the host):
-//   node pool : per node (bf+1) packed centroid rows of RB bytes (RB = row bytes padded to
-//               16), plus per row: BitFeature id, child node id, centroid popcount; per
-//               node: row count, leaf flag, prev/next leaf (the leaf chain).
-//   BF pool   : per BitFeature n_samples, the exact moments sum(ls) and sum(ls^2) (u64)
-//               and a slot word (tier | index) into one of three cluster-feature pools:
-//               cf8 / cf16 / cf32 = linear sums at 1/2/4 bytes per feature (the reference
-//               keeps the minimum dtype for n_samples, utils.py:25; leaf BitFeatures move
-//               up a tier when n_samples crosses 255 / 65535, tracking BitFeatures of
-//               internal nodes always live in cf32).
+// Data layout in HBM (flat pools indexed by node id, grown by the host):
+//   per node  : header {len, leaf, prev_leaf, next_leaf};
+//   per row   : packed centroid (RB bytes = row bytes padded to 16), its popcount, a
+//               "link" word (internal row: child node id; leaf row: cluster-feature slot)
+//               and a 32-byte RowMeta {BitFeature id, n_samples, CF slot, sum(ls), sum(ls^2)}.
+//               Everything an insertion needs about a row lives next to the row, so one
+//               level of the descent is ONE round of dependent memory accesses.
+//   CF pools  : cf8 / cf16 / cf32 = linear sums at 1/2/4 bytes per feature (the reference
+//               keeps the minimum dtype for n_samples, utils.py:25).  Leaf BitFeatures
+//               move up a tier when n_samples crosses 255 / 65535; tracking BitFeatures of
+//               internal nodes always live in cf32.
 //
-// Execution model: ONE 256-thread workgroup walks one tree and inserts a whole batch
-// with the reference's sequential semantics.  Inside an insert the work is data
-// parallel: 16 lanes x 16 B cover a 256-byte centroid row (16 rows per pass, DPP row
-// reduction of the AND-popcounts), keys are combined through LDS, the cluster-feature
-// update is one thread per 8 features.  All decisions use exact integers; the only
-// floating point is the reference's own f64 formulae, evaluated in the same order.
+// Execution model: one 256-thread workgroup per tree inserts a whole batch with the
+// reference's sequential semantics.  Inside an insert the work is data parallel: 16 lanes
+// x 16 B cover a 256-byte centroid row (16 rows per pass, DPP row reduction of the
+// AND-popcounts), per-row keys meet in LDS, the cluster-feature update is one thread per 8
+// features, and the leaf test + every ancestor's CF update share one block reduction.  The
+// root node is mirrored in LDS.  Everything wave-uniform (node ids, rows, lengths, slots)
+// is kept in SGPRs (readfirstlane / readlane), every pool access is an explicit
+// global-address-space access and every scratchpad access an LDS access, so the compiler
+// emits scalar control flow, global_load/ds_read and no private-memory traffic.
+// All decisions use exact integers; the only floating point is the reference's own f64
+// formulae in the same operation order.
 #include "bb_common.h"
 
 #include <algorithm>
@@ -36,13 +42,14 @@ namespace {
 constexpr int TB = 256;  // threads per tree workgroup
 constexpr int TW = TB / 64;
 constexpr uint32_t NONE = 0xFFFFFFFFu;
-constexpr int MAXD = 64;  // deepest tree handled
+constexpr int MAXD = 64;     // deepest tree handled
+constexpr int MAXFAST = 5;   // ancestor levels updated in the fused fast path
+constexpr int NRED = 2 + MAXFAST;
 constexpr int MAX_BF = 1023;
 
 enum StopReason : int32_t {
     STOP_DONE = 0,
     STOP_NODES = 1,
-    STOP_SUBS = 2,
     STOP_CF8 = 3,
     STOP_CF16 = 4,
     STOP_CF32 = 5,
@@ -50,7 +57,21 @@ enum StopReason : int32_t {
     STOP_RANGE = 7,  // n_samples would exceed 2^32-1
 };
 
-enum Ctr : int { C_NODES = 0, C_SUBS, C_N8, C_N16, C_N32, C_ROOT, C_FIRST_LEAF, C_DEPTH, C_COUNT };
+enum Ctr : int { C_NODES = 0, C_IDS, C_N8, C_N16, C_N32, C_ROOT, C_FIRST_LEAF, C_DEPTH, C_COUNT };
+
+struct __attribute__((aligned(16))) RowMeta {
+    uint32_t sub;   // BitFeature id (leaf rows; NONE for tracking rows)
+    uint32_t n;     // n_samples
+    uint32_t slot;  // tier << 30 | index into cf8/cf16/cf32
+    uint32_t pad;
+    unsigned long long s1;  // sum(ls)      (leaf rows)
+    unsigned long long s2;  // sum(ls^2)    (leaf rows)
+};
+static_assert(sizeof(RowMeta) == 32, "RowMeta must be 32 bytes");
+
+struct __attribute__((aligned(16))) NodeHdr {
+    uint32_t len, leaf, prev, next;
+};
 
 struct TreeDev {
     // configuration
@@ -60,369 +81,477 @@ struct TreeDev {
     const double* tol_table;
     // node pool
     uint8_t* node_cent;
-    uint32_t* node_sub;
-    uint32_t* node_child;
     uint32_t* node_card;
-    uint32_t* node_len;
-    uint32_t* node_prev;
-    uint32_t* node_next;
-    uint32_t* node_leaf;
+    uint32_t* node_link;
+    RowMeta* node_rm;
+    NodeHdr* node_hdr;
     uint8_t* scratch_cent;  // (bf+1) x RB, staging for row moves in a split
-    // BitFeature pool
-    uint32_t* sub_n;
-    unsigned long long* sub_s1;
-    unsigned long long* sub_s2;
-    uint32_t* sub_slot;
+    // cluster-feature pools
     uint8_t* cf8;
     uint16_t* cf16;
     uint32_t* cf32;
-    uint32_t cap_nodes, cap_subs, cap8, cap16, cap32;
+    uint32_t cap_nodes, cap8, cap16, cap32;
     // state
     uint32_t ctr[C_COUNT];
     unsigned long long stats[8];
-    // per launch result
+    unsigned long long phase[8];  // shader-clock cycles per phase (thread 0), debug
+    // job of the next launch
+    const uint8_t* rows;
+    long long row_stride;
+    const uint8_t* bufs;
+    int32_t width;
+    int32_t use_root_cache;
+    long long n_elems;
+    uint32_t* out_leaf;
+    // result of the last launch
     long long processed;
     int32_t stop_reason;
 };
 
-// -------------------------------------------------------------------------------------
-// device side
-// -------------------------------------------------------------------------------------
+// LDS layout: byte offsets from the start of the dynamic shared segment
 struct Smem {
-    uint4* x;        // packed centroid of the element being inserted, RB bytes
-    uint4* vec;      // comparison vector during a split
-    uint4* cA;       // centroid of tracking BitFeature A / B after a split
-    uint4* cB;
-    unsigned long long* keys;  // 2 x (bf+1)
-    uint32_t* child;           // 2 x (bf+1)
-    uint32_t* sub;             // 2 x (bf+1)
-    uint32_t* i1;              // (bf+1) each
-    uint32_t* u1;
-    uint32_t* i2;
-    uint32_t* u2;
-    uint32_t* dst;    // split: flag << 31 | destination row
-    uint32_t* mslot;  // split: slot word of each row's BitFeature
-    uint32_t* mn;     // split: n_samples of each row's BitFeature
-    uint32_t* msub;
-    uint32_t* mchild;
-    uint32_t* mcard;
-    unsigned long long* red;  // 2 x TW x 4
-    uint32_t* path_node;      // MAXD each
-    uint32_t* path_row;
-    uint32_t* path_sub;
-    uint32_t* path_len;
-    uint32_t* ctr;  // C_COUNT
-    unsigned long long* stats;
-    uint32_t* bc;  // broadcast scratch, 16
+    uint32_t x, vec, cA, cB;      // RB-byte vectors
+    uint32_t keys;                // 2 x rows u64
+    uint32_t link;                // 2 x rows u32
+    uint32_t i1, u1, i2, u2;      // rows u32 each (split)
+    uint32_t dst, mcard, mlink;   // rows u32 each (split)
+    uint32_t mrm;                 // rows x 32 B RowMeta images (split)
+    uint32_t red;                 // 2 x TW x NRED u64
+    uint32_t red32;               // 2 x TW x NRED u32
+    uint32_t wbest;               // 2 x TW u64: per-wave best candidate of a node compare
+    uint32_t path_node, path_row, path_len, path_slot, path_n;  // MAXD u32 each
+    uint32_t ctr;                 // C_COUNT u32
+    uint32_t stats;               // 8 u64
+    uint32_t bc;                  // 16 u32 broadcast scratch
+    uint32_t rc_cent, rc_card, rc_link;  // LDS mirror of the root node
+    uint32_t total;
 };
 
-__host__ __device__ inline size_t smem_layout(int bf, int RB, Smem* s, unsigned char* base) {
-    size_t off = 0;
+__host__ __device__ inline Smem smem_layout(int bf, int RB, bool root_cache) {
+    Smem s{};
+    uint32_t off = 0;
     auto take = [&](size_t bytes) {
-        size_t o = off;
-        off += (bytes + 15) / 16 * 16;
+        uint32_t o = off;
+        off += (uint32_t)((bytes + 15) / 16 * 16);
         return o;
     };
     const size_t m = (size_t)bf + 1;
-    size_t o_x = take(RB), o_vec = take(RB), o_cA = take(RB), o_cB = take(RB);
-    size_t o_keys = take(2 * m * 8), o_child = take(2 * m * 4), o_sub = take(2 * m * 4);
-    size_t o_i1 = take(m * 4), o_u1 = take(m * 4), o_i2 = take(m * 4), o_u2 = take(m * 4);
-    size_t o_dst = take(m * 4), o_mslot = take(m * 4), o_mn = take(m * 4), o_msub = take(m * 4);
-    size_t o_mchild = take(m * 4), o_mcard = take(m * 4);
-    size_t o_red = take(2 * TW * 4 * 8);
-    size_t o_pn = take(MAXD * 4), o_pr = take(MAXD * 4), o_ps = take(MAXD * 4), o_pl = take(MAXD * 4);
-    size_t o_ctr = take(C_COUNT * 4), o_stats = take(8 * 8), o_bc = take(16 * 4);
-    if (s) {
-        s->x = (uint4*)(base + o_x);
-        s->vec = (uint4*)(base + o_vec);
-        s->cA = (uint4*)(base + o_cA);
-        s->cB = (uint4*)(base + o_cB);
-        s->keys = (unsigned long long*)(base + o_keys);
-        s->child = (uint32_t*)(base + o_child);
-        s->sub = (uint32_t*)(base + o_sub);
-        s->i1 = (uint32_t*)(base + o_i1);
-        s->u1 = (uint32_t*)(base + o_u1);
-        s->i2 = (uint32_t*)(base + o_i2);
-        s->u2 = (uint32_t*)(base + o_u2);
-        s->dst = (uint32_t*)(base + o_dst);
-        s->mslot = (uint32_t*)(base + o_mslot);
-        s->mn = (uint32_t*)(base + o_mn);
-        s->msub = (uint32_t*)(base + o_msub);
-        s->mchild = (uint32_t*)(base + o_mchild);
-        s->mcard = (uint32_t*)(base + o_mcard);
-        s->red = (unsigned long long*)(base + o_red);
-        s->path_node = (uint32_t*)(base + o_pn);
-        s->path_row = (uint32_t*)(base + o_pr);
-        s->path_sub = (uint32_t*)(base + o_ps);
-        s->path_len = (uint32_t*)(base + o_pl);
-        s->ctr = (uint32_t*)(base + o_ctr);
-        s->stats = (unsigned long long*)(base + o_stats);
-        s->bc = (uint32_t*)(base + o_bc);
+    s.x = take(RB); s.vec = take(RB); s.cA = take(RB); s.cB = take(RB);
+    s.keys = take(2 * m * 8); s.link = take(2 * m * 4);
+    s.i1 = take(m * 4); s.u1 = take(m * 4); s.i2 = take(m * 4); s.u2 = take(m * 4);
+    s.dst = take(m * 4); s.mcard = take(m * 4); s.mlink = take(m * 4); s.mrm = take(m * 32);
+    s.red = take(2 * TW * NRED * 8);
+    s.red32 = take(2 * TW * NRED * 4);
+    s.wbest = take(2 * TW * 8);
+    s.path_node = take(MAXD * 4); s.path_row = take(MAXD * 4); s.path_len = take(MAXD * 4);
+    s.path_slot = take(MAXD * 4); s.path_n = take(MAXD * 4);
+    s.ctr = take(C_COUNT * 4); s.stats = take(8 * 8); s.bc = take(16 * 4);
+    if (root_cache) {
+        s.rc_cent = take(m * ((size_t)RB + 16));
+        s.rc_card = take(m * 4);
+        s.rc_link = take(m * 4);
     }
-    return off;
+    s.total = off;
+    return s;
 }
-
-struct Ctx {
-    TreeDev t;  // by-value copy of pointers and config (lives in SGPRs / scalar loads)
-    Smem s;
-    int RBc;           // 16-byte chunks per row
-    size_t node_rows;  // bf + 1
-    int red_slot;
-    int cmp_par;
-    // current element
-    const uint8_t* bufs;  // BitFeature buffer table (NULL = fingerprint mode)
-    int width;
-    long long elem;
-    uint32_t nS;
-    unsigned long long s1S, s2S;
-    uint32_t pcx;
-};
 
 #if defined(__HIPCC__)
 
-// ---- block reductions (sum of up to 4 u64 values to every thread) ---------------------
-__device__ __forceinline__ void block_sum4(Ctx& c, unsigned long long& a, unsigned long long& b,
-                                           unsigned long long& d, unsigned long long& e) {
-    a = wave_sum_u64(a);
-    b = wave_sum_u64(b);
-    d = wave_sum_u64(d);
-    e = wave_sum_u64(e);
-    unsigned long long* buf = c.s.red + (size_t)c.red_slot * TW * 4;
-    c.red_slot ^= 1;
+#define GA __attribute__((address_space(1)))
+#define LA __attribute__((address_space(3)))
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned long long u64;
+
+// explicit global / LDS accesses (the pools are reached through pointers loaded from
+// memory, which the compiler would otherwise treat as generic -> flat_load)
+template <typename T> __device__ __forceinline__ T ldg(const void* p) { return *(const GA T*)p; }
+template <typename T> __device__ __forceinline__ void stg(void* p, T v) { *(GA T*)p = v; }
+template <typename T> __device__ __forceinline__ LA T* lds(LA unsigned char* L, uint32_t off) { return (LA T*)(L + off); }
+
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ u64 uni64(u64 v) { return ((u64)uni((uint32_t)(v >> 32)) << 32) | uni((uint32_t)v); }
+__device__ __forceinline__ uint32_t rdlane(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
+
+__device__ __forceinline__ uint32_t popc4v(u32x4_t q) { return __popc(q.x) + __popc(q.y) + __popc(q.z) + __popc(q.w); }
+
+// wave reductions with a wave-uniform (SGPR) result: DPP inside the 16-lane rows, readlane across
+__device__ __forceinline__ uint32_t wsum32(uint32_t v) {
+    v = row16_sum(v);
+    return rdlane(v, 0) + rdlane(v, 16) + rdlane(v, 32) + rdlane(v, 48);
+}
+template <int N> __device__ __forceinline__ u64 ror64(u64 v) {
+    return ((u64)row_ror<N>((uint32_t)(v >> 32)) << 32) | row_ror<N>((uint32_t)v);
+}
+__device__ __forceinline__ u64 rdlane64(u64 v, int l) { return ((u64)rdlane((uint32_t)(v >> 32), l) << 32) | rdlane((uint32_t)v, l); }
+__device__ __forceinline__ u64 wsum64(u64 v) {
+    v += ror64<8>(v);
+    v += ror64<4>(v);
+    v += ror64<2>(v);
+    v += ror64<1>(v);
+    return rdlane64(v, 0) + rdlane64(v, 16) + rdlane64(v, 32) + rdlane64(v, 48);
+}
+__device__ __forceinline__ u64 wmax64(u64 v) {
+    u64 o;
+    o = ror64<8>(v); v = o > v ? o : v;
+    o = ror64<4>(v); v = o > v ? o : v;
+    o = ror64<2>(v); v = o > v ? o : v;
+    o = ror64<1>(v); v = o > v ? o : v;
+    const u64 a = rdlane64(v, 0), b = rdlane64(v, 16), c = rdlane64(v, 32), d = rdlane64(v, 48);
+    const u64 ab = a > b ? a : b, cd = c > d ? c : d;
+    return ab > cd ? ab : cd;
+}
+
+// uniform kernel context: plain values, fully scalarised after inlining
+struct KC {
+    uint8_t* cent; uint32_t* card; uint32_t* link; RowMeta* rm; NodeHdr* hdr; uint8_t* scratch;
+    uint8_t* cf8; uint16_t* cf16; uint32_t* cf32;
+    const uint8_t* bufs; int width;
+    int F, nb, RB, RBc, RBS;
+    uint32_t rows, bf;
+    int crit, tol_len; double thr, tolerance; const double* tol;
+    bool use_rc;
+    LA unsigned char* L;
+    Smem o;
+};
+struct Elem {  // the element being inserted (uniform)
+    long long idx; uint32_t nS; u64 s1S, s2S; uint32_t pcx;
+};
+
+// ---- block reduction of NV u64 values to every thread, uniform result (one barrier) ------
+template <int NV>
+__device__ __forceinline__ void block_sum(const KC& k, int& red_slot, u64 (&v)[NV]) {
+    LA u64* buf = lds<u64>(k.L, k.o.red) + red_slot * TW * NRED;
+    red_slot ^= 1;
     const int w = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) {
-        buf[w * 4 + 0] = a;
-        buf[w * 4 + 1] = b;
-        buf[w * 4 + 2] = d;
-        buf[w * 4 + 3] = e;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const u64 t = wsum64(v[i]);
+        if ((threadIdx.x & 63) == 0) buf[w * NRED + i] = t;
     }
     __syncthreads();
-    a = b = d = e = 0;
 #pragma unroll
-    for (int i = 0; i < TW; ++i) {
-        a += buf[i * 4 + 0];
-        b += buf[i * 4 + 1];
-        d += buf[i * 4 + 2];
-        e += buf[i * 4 + 3];
+    for (int i = 0; i < NV; ++i) {
+        u64 a = 0;
+#pragma unroll
+        for (int q = 0; q < TW; ++q) a += buf[q * NRED + i];
+        v[i] = uni64(a);
     }
 }
 
-__device__ __forceinline__ void block_sum2(Ctx& c, unsigned long long& a, unsigned long long& b) {
-    unsigned long long z0 = 0, z1 = 0;
-    block_sum4(c, a, b, z0, z1);
-}
-
-// ---- cluster-feature access: 8 consecutive features of one BitFeature ------------------
-__device__ __forceinline__ void cf_load8(const Ctx& c, uint32_t slotw, int b, uint32_t v[8]) {
+// ---- cluster-feature access: 8 consecutive features -----------------------------------
+__device__ __forceinline__ void cf_load8(const KC& k, uint32_t slotw, int b, uint32_t v[8]) {
     const uint32_t tier = slotw >> 30;
-    const size_t idx = (size_t)(slotw & 0x3FFFFFFFu) * (size_t)c.t.F + (size_t)b * 8;
+    const size_t idx = (size_t)(slotw & 0x3FFFFFFFu) * (size_t)k.F + (size_t)b * 8;
     if (tier == 0) {
-        uint2 q = *reinterpret_cast<const uint2*>(c.t.cf8 + idx);
+        const u32x2_t q = ldg<u32x2_t>(k.cf8 + idx);
         v[0] = q.x & 0xFF; v[1] = (q.x >> 8) & 0xFF; v[2] = (q.x >> 16) & 0xFF; v[3] = q.x >> 24;
         v[4] = q.y & 0xFF; v[5] = (q.y >> 8) & 0xFF; v[6] = (q.y >> 16) & 0xFF; v[7] = q.y >> 24;
     } else if (tier == 1) {
-        uint4 q = *reinterpret_cast<const uint4*>(c.t.cf16 + idx);
+        const u32x4_t q = ldg<u32x4_t>(k.cf16 + idx);
         v[0] = q.x & 0xFFFF; v[1] = q.x >> 16; v[2] = q.y & 0xFFFF; v[3] = q.y >> 16;
         v[4] = q.z & 0xFFFF; v[5] = q.z >> 16; v[6] = q.w & 0xFFFF; v[7] = q.w >> 16;
     } else {
-        const uint4* p = reinterpret_cast<const uint4*>(c.t.cf32 + idx);
-        uint4 q0 = p[0], q1 = p[1];
+        const u32x4_t q0 = ldg<u32x4_t>(k.cf32 + idx), q1 = ldg<u32x4_t>(k.cf32 + idx + 4);
         v[0] = q0.x; v[1] = q0.y; v[2] = q0.z; v[3] = q0.w;
         v[4] = q1.x; v[5] = q1.y; v[6] = q1.z; v[7] = q1.w;
     }
 }
 
-__device__ __forceinline__ void cf_store8(const Ctx& c, uint32_t slotw, int b, const uint32_t v[8]) {
+__device__ __forceinline__ void cf_store8(const KC& k, uint32_t slotw, int b, const uint32_t v[8]) {
     const uint32_t tier = slotw >> 30;
-    const size_t idx = (size_t)(slotw & 0x3FFFFFFFu) * (size_t)c.t.F + (size_t)b * 8;
+    const size_t idx = (size_t)(slotw & 0x3FFFFFFFu) * (size_t)k.F + (size_t)b * 8;
     if (tier == 0) {
-        uint2 q;
+        u32x2_t q;
         q.x = v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);
         q.y = v[4] | (v[5] << 8) | (v[6] << 16) | (v[7] << 24);
-        *reinterpret_cast<uint2*>(c.t.cf8 + idx) = q;
+        stg<u32x2_t>(k.cf8 + idx, q);
     } else if (tier == 1) {
-        uint4 q;
+        u32x4_t q;
         q.x = v[0] | (v[1] << 16); q.y = v[2] | (v[3] << 16);
         q.z = v[4] | (v[5] << 16); q.w = v[6] | (v[7] << 16);
-        *reinterpret_cast<uint4*>(c.t.cf16 + idx) = q;
+        stg<u32x4_t>(k.cf16 + idx, q);
     } else {
-        uint4* p = reinterpret_cast<uint4*>(c.t.cf32 + idx);
-        p[0] = make_uint4(v[0], v[1], v[2], v[3]);
-        p[1] = make_uint4(v[4], v[5], v[6], v[7]);
+        u32x4_t q0, q1;
+        q0.x = v[0]; q0.y = v[1]; q0.z = v[2]; q0.w = v[3];
+        q1.x = v[4]; q1.y = v[5]; q1.z = v[6]; q1.w = v[7];
+        stg<u32x4_t>(k.cf32 + idx, q0);
+        stg<u32x4_t>(k.cf32 + idx + 4, q1);
     }
 }
 
+// tracking BitFeatures always live in cf32: no tier dispatch on the hot path
+__device__ __forceinline__ void cf32_load8(const KC& k, uint32_t slotw, int b, uint32_t v[8]) {
+    const size_t idx = (size_t)(slotw & 0x3FFFFFFFu) * (size_t)k.F + (size_t)b * 8;
+    const u32x4_t q0 = ldg<u32x4_t>(k.cf32 + idx), q1 = ldg<u32x4_t>(k.cf32 + idx + 4);
+    v[0] = q0.x; v[1] = q0.y; v[2] = q0.z; v[3] = q0.w;
+    v[4] = q1.x; v[5] = q1.y; v[6] = q1.z; v[7] = q1.w;
+}
+
 // linear-sum values of the element being inserted for features b*8 .. b*8+7
-__device__ __forceinline__ void elem_cols(const Ctx& c, int b, uint32_t v[8]) {
-    if (c.bufs == nullptr) {  // fingerprint: bits of the packed row, MSB first
-        const uint32_t xb = reinterpret_cast<const uint8_t*>(c.s.x)[b];
+__device__ __forceinline__ void elem_cols(const KC& k, const Elem& el, int b, uint32_t v[8]) {
+    if (k.bufs == nullptr) {  // fingerprint: bits of the packed row, MSB first
+        const uint32_t xb = lds<uint8_t>(k.L, k.o.x)[b];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = (xb >> (7 - k)) & 1u;
+        for (int q = 0; q < 8; ++q) v[q] = (xb >> (7 - q)) & 1u;
         return;
     }
-    const size_t base = (size_t)c.elem * ((size_t)c.t.F + 1) + (size_t)b * 8;
+    const size_t base = (size_t)el.idx * ((size_t)k.F + 1) + (size_t)b * 8;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        switch (c.width) {
-            case 1: v[k] = c.bufs[base + k]; break;
-            case 2: v[k] = reinterpret_cast<const uint16_t*>(c.bufs)[base + k]; break;
-            case 4: v[k] = reinterpret_cast<const uint32_t*>(c.bufs)[base + k]; break;
-            default: v[k] = (uint32_t) reinterpret_cast<const unsigned long long*>(c.bufs)[base + k]; break;
+    for (int q = 0; q < 8; ++q) {
+        switch (k.width) {
+            case 1: v[q] = ldg<uint8_t>(k.bufs + base + q); break;
+            case 2: v[q] = ldg<uint16_t>(k.bufs + 2 * (base + q)); break;
+            case 4: v[q] = ldg<uint32_t>(k.bufs + 4 * (base + q)); break;
+            default: v[q] = (uint32_t)ldg<u64>(k.bufs + 8 * (base + q)); break;
         }
     }
 }
 
-// majority-vote byte for 8 features (centroid_from_sum, _py_similarity.py:36-41)
-__device__ __forceinline__ uint32_t centroid_byte(const uint32_t v[8], unsigned long long n) {
+// majority-vote byte for 8 features (centroid_from_sum, _py_similarity.py:36-41).
+// n fits in 32 bits by contract, 2*v is formed in 64 bits only when needed.
+__device__ __forceinline__ uint32_t centroid_byte(const uint32_t v[8], u64 n) {
     uint32_t byte = 0;
     if (n <= 1) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) byte |= ((v[k] & 0xFFu) != 0 ? 1u : 0u) << (7 - k);
+        for (int q = 0; q < 8; ++q) byte |= ((v[q] & 0xFFu) != 0 ? 1u : 0u) << (7 - q);
+    } else if (n <= 0x7FFFFFFFull) {
+        const uint32_t half = (uint32_t)((n + 1) >> 1);  // 2v >= n  <=>  v >= ceil(n/2)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) byte |= (v[q] >= half ? 1u : 0u) << (7 - q);
     } else {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) byte |= (2ull * v[k] >= n ? 1u : 0u) << (7 - k);
+        for (int q = 0; q < 8; ++q) byte |= (2ull * v[q] >= n ? 1u : 0u) << (7 - q);
     }
     return byte;
 }
 
-__device__ __forceinline__ uint32_t tier_for(unsigned long long n) { return n <= 255 ? 0u : (n <= 65535 ? 1u : 2u); }
+__device__ __forceinline__ uint32_t tier_for(u64 n) { return n <= 255 ? 0u : (n <= 65535 ? 1u : 2u); }
+__device__ __forceinline__ int ctr_for_tier(uint32_t tier) { return tier == 0 ? C_N8 : (tier == 1 ? C_N16 : C_N32); }
 
-// popcount of an RB-byte vector in LDS (every wave computes it redundantly)
-__device__ __forceinline__ uint32_t lds_vec_popcount(const Ctx& c, const uint4* v) {
+// popcount of an RB-byte vector in LDS (every wave computes it redundantly; uniform result)
+__device__ __forceinline__ uint32_t lds_vec_popcount(const KC& k, uint32_t off) {
     uint32_t p = 0;
-    for (int ch = threadIdx.x & 63; ch < c.RBc; ch += 64) p += popc4(v[ch]);
-    return wave_sum_u32(p);
+    for (int ch = threadIdx.x & 63; ch < k.RBc; ch += 64) p += popc4v(lds<u32x4_t>(k.L, off)[ch]);
+    return wsum32(p);
 }
 
-// ---- similarity of every row of a node against a vector in LDS -------------------------
-// mode 0: keys for first-argmax; mode 1: keys for first-argmin.  Ends with a barrier.
-__device__ void node_compare(Ctx& c, uint32_t nd, uint32_t len, const uint4* vec, uint32_t vec_pc, int mode,
-                             uint32_t* s_i, uint32_t* s_u, bool load_meta) {
+// A comparison candidate: Tanimoto = i / u as an exact fraction (u already clamped to >= 1,
+// similarity.cpp:326-331) and the row it belongs to.  Equal fractions <=> equal float64
+// quotients (both are the correctly rounded value of the same rational), distinct fractions
+// with u <= 2^14 differ by far more than an ulp, so ordering fractions by cross-multiplication
+// reproduces np.argmax / np.argmin on the reference's float64 array exactly, including the
+// first-index tie-break.
+struct Cand { uint32_t i, u, r; };
+
+template <bool MINMODE>
+__device__ __forceinline__ bool cand_better(uint32_t ai, uint32_t au, uint32_t ar, uint32_t bi, uint32_t bu, uint32_t br) {
+    const uint32_t x = ai * bu, y = bi * au;  // < 2^28
+    if (MINMODE) return x < y || (x == y && ar < br);
+    return x > y || (x == y && ar < br);
+}
+
+// ---- similarity of every row of a node against a vector in LDS; returns the first-argmax
+// (or first-argmin) row as a wave-uniform candidate.  Loads all bf+1 row slots without
+// waiting for the node's length (rows >= len are masked) so header and rows arrive in the
+// same memory round trip; popcounts of 16 lanes meet by DPP, the 4 row groups of a wave by
+// readlane, the 4 waves through 32 bytes of LDS and one barrier.
+template <bool ROOT, bool MINMODE>
+__device__ __forceinline__ Cand node_best(const KC& k, int& cmp_par, uint32_t nd, int known_len, uint32_t vec_off,
+                                          uint32_t vec_pc, bool want_counts, bool second, bool want_link,
+                                          uint32_t* out_len, uint32_t* out_leaf) {
     const int tid = threadIdx.x, l = tid & 15, g = tid >> 4;
-    const size_t rows = c.node_rows;
-    const uint8_t* base = c.t.node_cent + (size_t)nd * rows * (size_t)c.t.RB;
-    c.cmp_par ^= 1;
-    unsigned long long* keys = c.s.keys + (size_t)c.cmp_par * rows;
-    uint32_t* s_child = c.s.child + (size_t)c.cmp_par * rows;
-    uint32_t* s_sub = c.s.sub + (size_t)c.cmp_par * rows;
+    const uint32_t rows = k.rows;
+    cmp_par ^= 1;
+    LA uint32_t* s_link = lds<uint32_t>(k.L, k.o.link) + cmp_par * rows;
+    LA uint32_t* s_i = lds<uint32_t>(k.L, second ? k.o.i2 : k.o.i1);
+    LA uint32_t* s_u = lds<uint32_t>(k.L, second ? k.o.u2 : k.o.u1);
+    LA u64* wb = lds<u64>(k.L, k.o.wbest) + cmp_par * TW;
     const size_t meta = (size_t)nd * rows;
-    if (c.RBc == 16) {
-        const uint4 xv = vec[l];
-        for (uint32_t r0 = 0; r0 < len; r0 += 64) {
-            uint4 d[4];
+    uint32_t len = 0, leaf = 0;
+    u32x4_t hraw = (u32x4_t)(0);
+    const bool load_hdr = !ROOT && known_len < 0;
+    if (load_hdr) hraw = ldg<u32x4_t>(k.hdr + nd);  // issued before the rows, same round trip
+    LA u32x4_t* vec = lds<u32x4_t>(k.L, vec_off);
+    // running best of this lane's row group (identical in all 16 lanes of the group)
+    uint32_t bi = MINMODE ? 0xFFFFu : 0u, bu = 1u, br = NONE;
+    if (k.RBc == 16) {
+        const u32x4_t xv = vec[l];
+        for (uint32_t r0 = 0; r0 < rows; r0 += 64) {
+            u32x4_t d[4];
+            uint32_t cd[4];
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
                 const uint32_t r = r0 + p * 16 + g;
-                d[p] = make_uint4(0, 0, 0, 0);
-                if (r < len) d[p] = reinterpret_cast<const uint4*>(base + (size_t)r * 256)[l];
+                d[p] = (u32x4_t)(0);
+                cd[p] = 0;
+                if (r < rows) {
+                    if constexpr (ROOT) {
+                        d[p] = *(LA u32x4_t*)(k.L + k.o.rc_cent + r * k.RBS + l * 16);
+                        if (l == 0) cd[p] = lds<uint32_t>(k.L, k.o.rc_card)[r];
+                    } else {
+                        d[p] = ldg<u32x4_t>(k.cent + (meta + r) * 256 + l * 16);
+                        if (l == 0) {
+                            cd[p] = ldg<uint32_t>(k.card + meta + r);
+                            if (want_link) s_link[r] = ldg<uint32_t>(k.link + meta + r);
+                        }
+                    }
+                }
+            }
+            if (r0 == 0) {
+                if (load_hdr) {
+                    len = uni(hraw.x);
+                    leaf = uni(hraw.y);
+                } else {
+                    len = (uint32_t)known_len;
+                }
             }
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
                 const uint32_t r = r0 + p * 16 + g;
-                const uint32_t inter = row16_sum(popc4(and4(d[p], xv)));
-                if (r < len && l == 0) {
-                    const uint32_t un = c.t.node_card[meta + r] + vec_pc - inter;
-                    const unsigned long long bits = (unsigned long long)__double_as_longlong(jt_from_counts(inter, un));
-                    keys[r] = (bits & ~0xFFFull) | (unsigned long long)(mode == 0 ? (0xFFFu - r) : r);
-                    if (s_i) { s_i[r] = inter; s_u[r] = un; }
-                    if (load_meta) { s_child[r] = c.t.node_child[meta + r]; s_sub[r] = c.t.node_sub[meta + r]; }
-                }
+                // lane 0 of the group carries the row's cardinality in the high half
+                const uint32_t both = row16_sum(popc4v(d[p] & xv) + (cd[p] << 16));
+                const uint32_t inter = both & 0xFFFFu;
+                uint32_t un = (both >> 16) + vec_pc - inter;
+                if (want_counts && r < len && l == 0) { s_i[r] = inter; s_u[r] = un; }
+                un = un < 1u ? 1u : un;
+                if (r < len && cand_better<MINMODE>(inter, un, r, bi, bu, br)) { bi = inter; bu = un; br = r; }
             }
         }
     } else {
-        for (uint32_t r0 = 0; r0 < len; r0 += TB / 16) {
+        if (load_hdr) {
+            len = uni(hraw.x);
+            leaf = uni(hraw.y);
+        } else {
+            len = (uint32_t)known_len;
+        }
+        for (uint32_t r0 = 0; r0 < rows; r0 += TB / 16) {
             const uint32_t r = r0 + g;
-            uint32_t inter = 0;
+            uint32_t part = 0;
             if (r < len) {
-                const uint4* row = reinterpret_cast<const uint4*>(base + (size_t)r * c.t.RB);
-                for (int ch = l; ch < c.RBc; ch += 16) inter += popc4(and4(row[ch], vec[ch]));
+                for (int ch = l; ch < k.RBc; ch += 16) {
+                    u32x4_t d;
+                    if constexpr (ROOT) d = *(LA u32x4_t*)(k.L + k.o.rc_cent + r * k.RBS + ch * 16);
+                    else d = ldg<u32x4_t>(k.cent + (meta + r) * (size_t)k.RB + ch * 16);
+                    part += popc4v(d & vec[ch]);
+                }
+                if (l == 0) {
+                    if constexpr (ROOT) {
+                        part += lds<uint32_t>(k.L, k.o.rc_card)[r] << 16;
+                    } else {
+                        part += ldg<uint32_t>(k.card + meta + r) << 16;
+                        if (want_link) s_link[r] = ldg<uint32_t>(k.link + meta + r);
+                    }
+                }
             }
-            inter = row16_sum(inter);
-            if (r < len && l == 0) {
-                const uint32_t un = c.t.node_card[meta + r] + vec_pc - inter;
-                const unsigned long long bits = (unsigned long long)__double_as_longlong(jt_from_counts(inter, un));
-                keys[r] = (bits & ~0xFFFull) | (unsigned long long)(mode == 0 ? (0xFFFu - r) : r);
-                if (s_i) { s_i[r] = inter; s_u[r] = un; }
-                if (load_meta) { s_child[r] = c.t.node_child[meta + r]; s_sub[r] = c.t.node_sub[meta + r]; }
-            }
+            const uint32_t both = row16_sum(part);
+            const uint32_t inter = both & 0xFFFFu;
+            uint32_t un = (both >> 16) + vec_pc - inter;
+            if (want_counts && r < len && l == 0) { s_i[r] = inter; s_u[r] = un; }
+            un = un < 1u ? 1u : un;
+            if (r < len && cand_better<MINMODE>(inter, un, r, bi, bu, br)) { bi = inter; bu = un; br = r; }
         }
     }
-    __syncthreads();
-}
-
-// first index of the max (mode 0) / min (mode 1) similarity among the keys just written
-__device__ __forceinline__ uint32_t pick_best(const Ctx& c, uint32_t len, int mode) {
-    const unsigned long long* keys = c.s.keys + (size_t)c.cmp_par * c.node_rows;
-    unsigned long long k = mode == 0 ? 0ull : ~0ull;
-    for (uint32_t r = threadIdx.x & 63; r < len; r += 64) {
-        const unsigned long long v = keys[r];
-        k = mode == 0 ? (v > k ? v : k) : (v < k ? v : k);
+    // the 4 row groups of this wave (scalar from here on)
+    uint32_t wi = rdlane(bi, 0), wu = rdlane(bu, 0), wr = rdlane(br, 0);
+#pragma unroll
+    for (int q = 16; q < 64; q += 16) {
+        const uint32_t ci = rdlane(bi, q), cu = rdlane(bu, q), cr = rdlane(br, q);
+        if (cand_better<MINMODE>(ci, cu, cr, wi, wu, wr)) { wi = ci; wu = cu; wr = cr; }
     }
-    k = mode == 0 ? wave_max_u64(k) : wave_min_u64(k);
-    const uint32_t low = (uint32_t)(k & 0xFFFull);
-    return mode == 0 ? (0xFFFu - low) : low;
+    if ((tid & 63) == 0) wb[tid >> 6] = ((u64)wr << 32) | (wi << 16) | wu;
+    __syncthreads();
+    Cand best;
+    {
+        const u64 v0 = wb[0];
+        best.r = uni((uint32_t)(v0 >> 32));
+        best.i = uni((uint32_t)v0) >> 16;
+        best.u = uni((uint32_t)v0) & 0xFFFFu;
+    }
+#pragma unroll
+    for (int w = 1; w < TW; ++w) {
+        const u64 v = wb[w];
+        const uint32_t cr = uni((uint32_t)(v >> 32)), lo = uni((uint32_t)v);
+        const uint32_t ci = lo >> 16, cu = lo & 0xFFFFu;
+        if (cand_better<MINMODE>(ci, cu, cr, best.i, best.u, best.r)) { best.i = ci; best.u = cu; best.r = cr; }
+    }
+    if (out_len) *out_len = len;
+    if (out_leaf) *out_leaf = leaf;
+    return best;
 }
 
-// write one node row: centroid (from LDS), popcount, BitFeature id, child node id
-__device__ __forceinline__ void node_put_row(const Ctx& c, uint32_t nd, uint32_t row, const uint4* cent, uint32_t card,
-                                             uint32_t sub, uint32_t child) {
-    uint4* dstp = reinterpret_cast<uint4*>(c.t.node_cent + ((size_t)nd * c.node_rows + row) * (size_t)c.t.RB);
-    for (int ch = threadIdx.x; ch < c.RBc; ch += TB) dstp[ch] = cent[ch];
+// write one node row: centroid (from LDS), popcount, link, meta
+__device__ __forceinline__ void node_put_row(const KC& k, uint32_t nd, uint32_t row, uint32_t cent_off, uint32_t card,
+                                             uint32_t link, uint32_t sub, uint32_t n, uint32_t slot, u64 s1, u64 s2) {
+    const size_t m = (size_t)nd * k.rows + row;
+    for (int ch = threadIdx.x; ch < k.RBc; ch += TB)
+        stg<u32x4_t>(k.cent + m * (size_t)k.RB + (size_t)ch * 16, lds<u32x4_t>(k.L, cent_off)[ch]);
     if (threadIdx.x == 0) {
-        const size_t m = (size_t)nd * c.node_rows + row;
-        c.t.node_card[m] = card;
-        c.t.node_sub[m] = sub;
-        c.t.node_child[m] = child;
+        stg<uint32_t>(k.card + m, card);
+        stg<uint32_t>(k.link + m, link);
+        u32x4_t a, b;
+        a.x = sub; a.y = n; a.z = slot; a.w = 0;
+        b.x = (uint32_t)s1; b.y = (uint32_t)(s1 >> 32); b.z = (uint32_t)s2; b.w = (uint32_t)(s2 >> 32);
+        stg<u32x4_t>((uint8_t*)(k.rm + m), a);
+        stg<u32x4_t>((uint8_t*)(k.rm + m) + 16, b);
+    }
+}
+
+// copy the root node into its LDS mirror (caller provides the barriers around it)
+__device__ __forceinline__ void root_mirror_load(const KC& k, uint32_t root) {
+    const size_t meta = (size_t)root * k.rows;
+    for (uint32_t i = threadIdx.x; i < k.rows * (uint32_t)k.RBc; i += TB) {
+        const uint32_t r = i / k.RBc, ch = i % k.RBc;
+        *(LA u32x4_t*)(k.L + k.o.rc_cent + r * k.RBS + ch * 16) =
+            ldg<u32x4_t>(k.cent + (meta + r) * (size_t)k.RB + (size_t)ch * 16);
+    }
+    for (uint32_t r = threadIdx.x; r < k.rows; r += TB) {
+        lds<uint32_t>(k.L, k.o.rc_card)[r] = ldg<uint32_t>(k.card + meta + r);
+        lds<uint32_t>(k.L, k.o.rc_link)[r] = ldg<uint32_t>(k.link + meta + r);
     }
 }
 
 // ---- radius complement terms (similarity.py:192-202) on CF(slot) [+ element] -----------
-// returns sum(c) and sum(2*v*c + c) where c = majority bit of v for n >= 2
-__device__ void radius_terms(Ctx& c, uint32_t slotw, bool add_elem, unsigned long long n,
-                             unsigned long long& sc, unsigned long long& sq) {
-    unsigned long long a = 0, q = 0;
-    const int nb = c.t.nbytes;
-    for (int b = threadIdx.x; b < nb; b += TB) {
+__device__ __forceinline__ void radius_terms(const KC& k, const Elem& el, int& red_slot, uint32_t slotw, bool add_elem,
+                                             u64 n, u64& sc, u64& sq) {
+    u64 acc[2] = {0, 0};
+    for (int b = threadIdx.x; b < k.nb; b += TB) {
         uint32_t v[8], e[8];
-        cf_load8(c, slotw, b, v);
+        cf_load8(k, slotw, b, v);
         if (add_elem) {
-            elem_cols(c, b, e);
+            elem_cols(k, el, b, e);
 #pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] += e[k];
+            for (int q = 0; q < 8; ++q) v[q] += e[q];
         }
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const unsigned long long vv = v[k];
-            const unsigned long long bit = n <= 1 ? (unsigned long long)((vv & 0xFF) != 0) : (2ull * vv >= n ? 1ull : 0ull);
-            // reference adds the centroid VALUE (cast) for n<=1; it is 0/1 in every reachable case
-            a += bit;
-            q += 2ull * vv * bit + bit;
+        for (int q = 0; q < 8; ++q) {
+            const u64 vv = v[q];
+            const u64 bit = n <= 1 ? (u64)((vv & 0xFF) != 0) : (2ull * vv >= n ? 1ull : 0ull);
+            acc[0] += bit;
+            acc[1] += 2ull * vv * bit + bit;
         }
     }
-    block_sum2(c, a, q);
-    sc = a;
-    sq = q;
+    block_sum<2>(k, red_slot, acc);
+    sc = acc[0];
+    sq = acc[1];
 }
 
-__device__ __forceinline__ double radius_compl(unsigned long long s1, unsigned long long s2, unsigned long long sc,
-                                               unsigned long long sq, unsigned long long n) {
+__device__ __forceinline__ double radius_compl(u64 s1, u64 s2, u64 sc, u64 sq, u64 n) {
     const double jt = isim_from_moments(s1, s2, n);
     const double jt1 = isim_from_moments(s1 + sc, s2 + sq, n + 1);
     return (jt1 * (double)(n + 1) - jt * (double)(n - 1)) / 2;
 }
 
-__device__ __forceinline__ double tol_lookup(const Ctx& c, unsigned long long old_n) {
-    if (c.t.tol_table == nullptr || old_n >= (unsigned long long)c.t.tol_len) return 0.0;
-    return c.t.tol_table[old_n];
+__device__ __forceinline__ double tol_lookup(const KC& k, u64 old_n) {
+    if (k.tol == nullptr || old_n >= (u64)k.tol_len) return 0.0;
+    return ldg<double>(k.tol + old_n);
 }
 
 // merge_accept_fn(threshold, new_ls, new_n, old_ls, nom_ls, old_n, nom_n) of _merges.py,
 // on exact moments.  Uniform across the block.
-__device__ bool merge_accept(Ctx& c, uint32_t slotT, unsigned long long nT, unsigned long long s1T,
-                             unsigned long long s2T, unsigned long long new_n, unsigned long long s1n,
-                             unsigned long long s2n) {
-    const double thr = c.t.thr;
-    switch (c.t.crit) {
+__device__ __forceinline__ bool merge_accept(const KC& k, const Elem& el, int& red_slot, uint32_t slotT, u64 nT, u64 s1T,
+                                             u64 s2T, u64 new_n, u64 s1n, u64 s2n) {
+    const double thr = k.thr;
+    switch (k.crit) {
         case BBH_CRIT_DIAMETER:
             return isim_from_moments(s1n, s2n, new_n) >= thr;
         case BBH_CRIT_TOL_DIAMETER: {
@@ -430,29 +559,29 @@ __device__ bool merge_accept(Ctx& c, uint32_t slotT, unsigned long long nT, unsi
             if (new_dc < thr) return false;
             if (nT == 1) return true;
             const double old_dc = isim_from_moments(s1T, s2T, nT);
-            return new_dc >= old_dc - tol_lookup(c, nT);
+            return new_dc >= old_dc - tol_lookup(k, nT);
         }
         case BBH_CRIT_TOL_LEGACY: {
             const double new_dc = isim_from_moments(s1n, s2n, new_n);
             if (new_dc < thr) return false;
-            if (nT == 1 || c.nS != 1) return true;
+            if (nT == 1 || el.nS != 1) return true;
             const double old_dc = isim_from_moments(s1T, s2T, nT);
-            return (new_dc * (double)new_n - old_dc * (double)(nT - 1)) / 2 >= old_dc - c.t.tolerance;
+            return (new_dc * (double)new_n - old_dc * (double)(nT - 1)) / 2 >= old_dc - k.tolerance;
         }
         case BBH_CRIT_RADIUS: {
-            unsigned long long sc, sq;
-            radius_terms(c, slotT, true, new_n, sc, sq);
+            u64 sc, sq;
+            radius_terms(k, el, red_slot, slotT, true, new_n, sc, sq);
             return radius_compl(s1n, s2n, sc, sq, new_n) >= thr;
         }
         case BBH_CRIT_TOL_RADIUS: {
-            unsigned long long sc, sq;
-            radius_terms(c, slotT, true, new_n, sc, sq);
+            u64 sc, sq;
+            radius_terms(k, el, red_slot, slotT, true, new_n, sc, sq);
             const double new_rc = radius_compl(s1n, s2n, sc, sq, new_n);
-            if (new_rc < thr) return false;  // uniform: every thread took part in the reduction above
+            if (new_rc < thr) return false;
             if (nT == 1) return true;
-            radius_terms(c, slotT, false, nT, sc, sq);
+            radius_terms(k, el, red_slot, slotT, false, nT, sc, sq);
             const double old_rc = radius_compl(s1T, s2T, sc, sq, nT);
-            return new_rc >= old_rc - tol_lookup(c, nT);
+            return new_rc >= old_rc - tol_lookup(k, nT);
         }
         default:
             return false;  // never-merge
@@ -461,189 +590,244 @@ __device__ bool merge_accept(Ctx& c, uint32_t slotT, unsigned long long nT, unsi
 
 // ---- _split_node (bitbirch.py:162-211) -------------------------------------------------
 // Splits node `nd` (len = bf+1 rows).  Leaves the two tracking BitFeatures' centroids in
-// s.cA / s.cB and returns ids through s.bc: [0]=node1 [1]=A [2]=B [3]=cardA [4]=cardB.
-__device__ void split_node(Ctx& c, uint32_t nd) {
+// LDS (o.cA / o.cB) and publishes through bc: [0]=node1 [3]=cardA [4]=cardB [7]=nA [8]=nB
+// [9]=slotA [10]=slotB [11]=n overflow flag.
+__device__ __forceinline__ void split_node(const KC& k, int& red_slot, int& cmp_par, uint32_t nd, uint32_t& cN,
+                                           uint32_t& c32, uint32_t& cFirst) {
     const int tid = threadIdx.x;
-    const uint32_t m = c.t.node_len[nd];
-    const size_t rows = c.node_rows;
+    const uint32_t rows = k.rows;
     const size_t meta = (size_t)nd * rows;
-    const int nb = c.t.nbytes;
-    uint8_t* cent = c.t.node_cent + meta * (size_t)c.t.RB;
+    const uint32_t m = uni(ldg<uint32_t>(k.hdr + nd));  // NodeHdr.len
+    const int nb = k.nb;
+    uint8_t* cent = k.cent + meta * (size_t)k.RB;
+    LA uint32_t* bc = lds<uint32_t>(k.L, k.o.bc);
+    LA uint32_t* dst = lds<uint32_t>(k.L, k.o.dst);
+    LA uint32_t* mcard = lds<uint32_t>(k.L, k.o.mcard);
+    LA uint32_t* mlink = lds<uint32_t>(k.L, k.o.mlink);
+    LA u32x4_t* mrm = lds<u32x4_t>(k.L, k.o.mrm);
+    LA u32x4_t* vec = lds<u32x4_t>(k.L, k.o.vec);
     // 0. row metadata to LDS; zero the comparison vector padding
     for (uint32_t r = tid; r < m; r += TB) {
-        const uint32_t sb = c.t.node_sub[meta + r];
-        c.s.msub[r] = sb;
-        c.s.mchild[r] = c.t.node_child[meta + r];
-        c.s.mcard[r] = c.t.node_card[meta + r];
-        c.s.mslot[r] = c.t.sub_slot[sb];
-        c.s.mn[r] = c.t.sub_n[sb];
+        mcard[r] = ldg<uint32_t>(k.card + meta + r);
+        mlink[r] = ldg<uint32_t>(k.link + meta + r);
+        mrm[2 * r] = ldg<u32x4_t>((uint8_t*)(k.rm + meta + r));
+        mrm[2 * r + 1] = ldg<u32x4_t>((uint8_t*)(k.rm + meta + r) + 16);
     }
-    for (int ch = tid; ch < c.RBc; ch += TB) c.s.vec[ch] = make_uint4(0, 0, 0, 0);
+    for (int ch = tid; ch < k.RBc; ch += TB) vec[ch] = (u32x4_t)(0);
     __syncthreads();
     // 1. majority centroid of the node's centroids (column sums of the unpacked rows)
     for (int b = tid; b < nb; b += TB) {
         uint32_t acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         for (uint32_t r = 0; r < m; ++r) {
-            const uint32_t v = cent[(size_t)r * c.t.RB + b];
+            const uint32_t v = ldg<uint8_t>(cent + (size_t)r * k.RB + b);
 #pragma unroll
-            for (int k = 0; k < 8; ++k) acc[k] += (v >> (7 - k)) & 1u;
+            for (int q = 0; q < 8; ++q) acc[q] += (v >> (7 - q)) & 1u;
         }
-        reinterpret_cast<uint8_t*>(c.s.vec)[b] = (uint8_t)centroid_byte(acc, m);
+        lds<uint8_t>(k.L, k.o.vec)[b] = (uint8_t)centroid_byte(acc, m);
     }
     __syncthreads();
-    uint32_t pc = lds_vec_popcount(c, c.s.vec);
+    const uint32_t pc = lds_vec_popcount(k, k.o.vec);
     // 2. fp1 = first argmin of similarity to that centroid
-    node_compare(c, nd, m, c.s.vec, pc, 1, nullptr, nullptr, false);
-    const uint32_t f1 = pick_best(c, m, 1);
+    const uint32_t f1 = node_best<false, true>(k, cmp_par, nd, (int)m, k.o.vec, pc, false, false, false, nullptr, nullptr).r;
     // 3. similarities to fp1; fp2 = first argmin
-    for (int ch = tid; ch < c.RBc; ch += TB) c.s.vec[ch] = reinterpret_cast<const uint4*>(cent + (size_t)f1 * c.t.RB)[ch];
+    for (int ch = tid; ch < k.RBc; ch += TB) vec[ch] = ldg<u32x4_t>(cent + (size_t)f1 * k.RB + (size_t)ch * 16);
     __syncthreads();
-    node_compare(c, nd, m, c.s.vec, c.s.mcard[f1], 1, c.s.i1, c.s.u1, false);
-    const uint32_t f2 = pick_best(c, m, 1);
+    const uint32_t f2 = node_best<false, true>(k, cmp_par, nd, (int)m, k.o.vec, uni(mcard[f1]), true, false, false, nullptr, nullptr).r;
     // 4. similarities to fp2
-    for (int ch = tid; ch < c.RBc; ch += TB) c.s.vec[ch] = reinterpret_cast<const uint4*>(cent + (size_t)f2 * c.t.RB)[ch];
+    for (int ch = tid; ch < k.RBc; ch += TB) vec[ch] = ldg<u32x4_t>(cent + (size_t)f2 * k.RB + (size_t)ch * 16);
     __syncthreads();
-    node_compare(c, nd, m, c.s.vec, c.s.mcard[f2], 1, c.s.i2, c.s.u2, false);
+    (void)node_best<false, true>(k, cmp_par, nd, (int)m, k.o.vec, uni(mcard[f2]), true, true, false, nullptr, nullptr);
     // 5. node1_closer = sims_fp1 > sims_fp2 (exact cross-multiplication), node1_closer[fp1] = True
-    for (uint32_t r = tid; r < m; r += TB) {
-        const uint32_t a1 = c.s.i1[r], b1 = c.s.u1[r] < 1u ? 1u : c.s.u1[r];
-        const uint32_t a2 = c.s.i2[r], b2 = c.s.u2[r] < 1u ? 1u : c.s.u2[r];
-        const bool to1 = ((unsigned long long)a1 * b2 > (unsigned long long)a2 * b1) || r == f1;
-        c.s.dst[r] = to1 ? 0x80000000u : 0u;
+    {
+        LA uint32_t* i1 = lds<uint32_t>(k.L, k.o.i1);
+        LA uint32_t* u1 = lds<uint32_t>(k.L, k.o.u1);
+        LA uint32_t* i2 = lds<uint32_t>(k.L, k.o.i2);
+        LA uint32_t* u2 = lds<uint32_t>(k.L, k.o.u2);
+        for (uint32_t r = tid; r < m; r += TB) {
+            const uint32_t a1 = i1[r], b1 = u1[r] < 1u ? 1u : u1[r];
+            const uint32_t a2 = i2[r], b2 = u2[r] < 1u ? 1u : u2[r];
+            const bool to1 = ((u64)a1 * b2 > (u64)a2 * b1) || r == f1;
+            dst[r] = to1 ? 0x80000000u : 0u;
+        }
     }
     __syncthreads();
     if (tid == 0) {
         uint32_t n1 = 0, n2 = 0;
-        unsigned long long nA = 0, nB = 0;
+        u64 nA = 0, nB = 0;
         for (uint32_t r = 0; r < m; ++r) {
-            if (c.s.dst[r] & 0x80000000u) {
-                c.s.dst[r] = 0x80000000u | n1++;
-                nA += c.s.mn[r];
+            const uint32_t nr = mrm[2 * r].y;  // RowMeta.n
+            if (dst[r] & 0x80000000u) {
+                dst[r] = 0x80000000u | n1++;
+                nA += nr;
             } else {
-                c.s.dst[r] = n2++;
-                nB += c.s.mn[r];
+                dst[r] = n2++;
+                nB += nr;
             }
         }
-        // 6. ids for the new node and the two tracking BitFeatures (always cf32)
-        const uint32_t node1 = c.s.ctr[C_NODES]++;
-        const uint32_t A = c.s.ctr[C_SUBS], B = A + 1;
-        c.s.ctr[C_SUBS] += 2;
-        const uint32_t slotA = c.s.ctr[C_N32], slotB = slotA + 1;
-        c.s.ctr[C_N32] += 2;
-        c.s.bc[0] = node1;
-        c.s.bc[1] = A;
-        c.s.bc[2] = B;
-        c.s.bc[5] = n1;
-        c.s.bc[6] = n2;
-        c.s.bc[7] = (uint32_t)nA;
-        c.s.bc[8] = (uint32_t)nB;
-        c.s.bc[9] = slotA;
-        c.s.bc[10] = slotB;
-        c.t.sub_n[A] = (uint32_t)nA;
-        c.t.sub_n[B] = (uint32_t)nB;
-        c.t.sub_slot[A] = (2u << 30) | slotA;
-        c.t.sub_slot[B] = (2u << 30) | slotB;
-        c.t.sub_s1[A] = c.t.sub_s2[A] = c.t.sub_s1[B] = c.t.sub_s2[B] = 0;
-        // 9. leaf chain: node1 goes immediately before nd (bitbirch.py:182-188)
-        const uint32_t leaf = c.t.node_leaf[nd];
-        c.t.node_leaf[node1] = leaf;
-        c.t.node_len[node1] = n1;
-        c.t.node_len[nd] = n2;
-        if (leaf) {
-            const uint32_t prev = c.t.node_prev[nd];
-            c.t.node_prev[node1] = prev;
-            if (prev != NONE) c.t.node_next[prev] = node1; else c.s.ctr[C_FIRST_LEAF] = node1;
-            c.t.node_next[node1] = nd;
-            c.t.node_prev[nd] = node1;
-        } else {
-            c.t.node_prev[node1] = NONE;
-            c.t.node_next[node1] = NONE;
-        }
-        c.s.stats[4]++;
-        c.s.stats[5]++;
+        bc[7] = (uint32_t)nA;
+        bc[8] = (uint32_t)nB;
+        bc[11] = (nA > 0xFFFFFFFFull || nB > 0xFFFFFFFFull) ? 1u : 0u;
+        bc[5] = n1;
+        bc[6] = n2;
+        lds<u64>(k.L, k.o.stats)[4]++;
+        lds<u64>(k.L, k.o.stats)[5]++;
     }
-    // 7a. stage all centroid rows (the kept ones are compacted in place afterwards)
-    for (size_t i = tid; i < (size_t)m * c.RBc; i += TB)
-        reinterpret_cast<uint4*>(c.t.scratch_cent)[i] = reinterpret_cast<const uint4*>(cent)[i];
+    // 6. ids for the new node and the two tracking BitFeatures (always cf32): every thread
+    //    keeps the (uniform) allocation counters in registers
+    const uint32_t node1 = cN++;
+    const uint32_t slotA_i = c32, slotB_i = c32 + 1;
+    c32 += 2;
+    const u32x4_t hold = ldg<u32x4_t>(k.hdr + nd);  // {len, leaf, prev, next}
+    const uint32_t was_leaf = uni(hold.y), prev_leaf = uni(hold.z);
+    if (was_leaf && prev_leaf == NONE) cFirst = node1;
+    // 7a. stage all centroid rows (kept rows are compacted in place afterwards)
+    for (uint32_t i = tid; i < m * (uint32_t)k.RBc; i += TB)
+        stg<u32x4_t>(k.scratch + (size_t)i * 16, ldg<u32x4_t>(cent + (size_t)i * 16));
     __syncthreads();
-    const uint32_t node1 = c.s.bc[0];
-    const unsigned long long nA = c.s.bc[7], nB = c.s.bc[8];
-    const uint32_t slotA = (2u << 30) | c.s.bc[9], slotB = (2u << 30) | c.s.bc[10];
+    const u64 nA = uni(bc[7]), nB = uni(bc[8]);
+    const uint32_t slotA = (2u << 30) | slotA_i, slotB = (2u << 30) | slotB_i;
+    if (tid == 0) {
+        // 9. leaf chain: node1 goes immediately before nd (bitbirch.py:182-188)
+        bc[0] = node1;
+        bc[9] = slotA_i;
+        bc[10] = slotB_i;
+        u32x4_t h = hold, h1;
+        h1.x = bc[5]; h1.y = h.y; h1.z = NONE; h1.w = NONE;
+        h.x = bc[6];
+        if (h.y) {
+            h1.z = h.z;
+            if (h.z != NONE) stg<uint32_t>((uint8_t*)(k.hdr + h.z) + 12, node1);
+            h1.w = nd;
+            h.z = node1;
+        }
+        stg<u32x4_t>(k.hdr + node1, h1);
+        stg<u32x4_t>(k.hdr + nd, h);
+    }
     // 7b. distribute rows in their original order
     {
-        uint8_t* cent1 = c.t.node_cent + (size_t)node1 * rows * (size_t)c.t.RB;
-        for (size_t i = tid; i < (size_t)m * c.RBc; i += TB) {
-            const uint32_t r = (uint32_t)(i / c.RBc), ch = (uint32_t)(i % c.RBc);
-            const uint32_t d = c.s.dst[r];
+        uint8_t* cent1 = k.cent + (size_t)node1 * rows * (size_t)k.RB;
+        for (uint32_t i = tid; i < m * (uint32_t)k.RBc; i += TB) {
+            const uint32_t r = i / k.RBc, ch = i % k.RBc;
+            const uint32_t d = dst[r];
             uint8_t* dstbase = (d & 0x80000000u) ? cent1 : cent;
-            reinterpret_cast<uint4*>(dstbase + (size_t)(d & 0x7FFFFFFFu) * c.t.RB)[ch] =
-                reinterpret_cast<const uint4*>(c.t.scratch_cent)[i];
+            stg<u32x4_t>(dstbase + (size_t)(d & 0x7FFFFFFFu) * k.RB + (size_t)ch * 16, ldg<u32x4_t>(k.scratch + (size_t)i * 16));
         }
         for (uint32_t r = tid; r < m; r += TB) {
-            const uint32_t d = c.s.dst[r];
+            const uint32_t d = dst[r];
             const size_t mm = ((d & 0x80000000u) ? (size_t)node1 * rows : meta) + (d & 0x7FFFFFFFu);
-            c.t.node_sub[mm] = c.s.msub[r];
-            c.t.node_child[mm] = c.s.mchild[r];
-            c.t.node_card[mm] = c.s.mcard[r];
+            stg<uint32_t>(k.card + mm, mcard[r]);
+            stg<uint32_t>(k.link + mm, mlink[r]);
+            stg<u32x4_t>((uint8_t*)(k.rm + mm), mrm[2 * r]);
+            stg<u32x4_t>((uint8_t*)(k.rm + mm) + 16, mrm[2 * r + 1]);
         }
     }
     // 8. tracking BitFeatures: CF = sum of member CFs; centroid from the final CF
-    for (int ch = tid; ch < c.RBc; ch += TB) {
-        c.s.cA[ch] = make_uint4(0, 0, 0, 0);
-        c.s.cB[ch] = make_uint4(0, 0, 0, 0);
+    for (int ch = tid; ch < k.RBc; ch += TB) {
+        lds<u32x4_t>(k.L, k.o.cA)[ch] = (u32x4_t)(0);
+        lds<u32x4_t>(k.L, k.o.cB)[ch] = (u32x4_t)(0);
     }
     __syncthreads();
-    unsigned long long cardA = 0, cardB = 0;
+    u64 cards[2] = {0, 0};
     for (int b = tid; b < nb; b += TB) {
         uint32_t accA[8] = {0, 0, 0, 0, 0, 0, 0, 0}, accB[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         for (uint32_t r = 0; r < m; ++r) {
             uint32_t v[8];
-            cf_load8(c, c.s.mslot[r], b, v);
-            if (c.s.dst[r] & 0x80000000u) {
+            cf_load8(k, uni(mrm[2 * r].z), b, v);  // RowMeta.slot
+            if (uni(dst[r]) & 0x80000000u) {
 #pragma unroll
-                for (int k = 0; k < 8; ++k) accA[k] += v[k];
+                for (int q = 0; q < 8; ++q) accA[q] += v[q];
             } else {
 #pragma unroll
-                for (int k = 0; k < 8; ++k) accB[k] += v[k];
+                for (int q = 0; q < 8; ++q) accB[q] += v[q];
             }
         }
-        cf_store8(c, slotA, b, accA);
-        cf_store8(c, slotB, b, accB);
+        cf_store8(k, slotA, b, accA);
+        cf_store8(k, slotB, b, accB);
         const uint32_t ba = centroid_byte(accA, nA), bb_ = centroid_byte(accB, nB);
-        reinterpret_cast<uint8_t*>(c.s.cA)[b] = (uint8_t)ba;
-        reinterpret_cast<uint8_t*>(c.s.cB)[b] = (uint8_t)bb_;
-        cardA += __popc(ba);
-        cardB += __popc(bb_);
+        lds<uint8_t>(k.L, k.o.cA)[b] = (uint8_t)ba;
+        lds<uint8_t>(k.L, k.o.cB)[b] = (uint8_t)bb_;
+        cards[0] += __popc(ba);
+        cards[1] += __popc(bb_);
     }
-    block_sum2(c, cardA, cardB);  // barrier inside: cA / cB complete for every thread
+    block_sum<2>(k, red_slot, cards);  // barrier inside: cA / cB complete for every thread
     if (tid == 0) {
-        c.s.bc[3] = (uint32_t)cardA;
-        c.s.bc[4] = (uint32_t)cardB;
+        bc[3] = (uint32_t)cards[0];
+        bc[4] = (uint32_t)cards[1];
     }
     __syncthreads();
 }
 
+// CF += element on one ancestor row (closest_subcluster.update, bitbirch.py:352-357); slow path
+__device__ __forceinline__ void update_tracker_slow(const KC& k, const Elem& el, int& red_slot, int lvl, int& stop) {
+    const int tid = threadIdx.x;
+    const uint32_t P = uni(lds<uint32_t>(k.L, k.o.path_node)[lvl]), jp = uni(lds<uint32_t>(k.L, k.o.path_row)[lvl]);
+    const size_t pm = (size_t)P * k.rows + jp;
+    const uint32_t slotw = uni(lds<uint32_t>(k.L, k.o.path_slot)[lvl]);
+    const u64 n_new = (u64)uni(lds<uint32_t>(k.L, k.o.path_n)[lvl]) + el.nS;
+    u64 cc[1] = {0};
+    for (int b = tid; b < k.nb; b += TB) {
+        uint32_t v[8], x8[8];
+        cf32_load8(k, slotw, b, v);
+        elem_cols(k, el, b, x8);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] += x8[q];
+        cf_store8(k, slotw, b, v);
+        const uint32_t byte = centroid_byte(v, n_new);
+        stg<uint8_t>(k.cent + pm * (size_t)k.RB + b, (uint8_t)byte);
+        cc[0] += __popc(byte);
+    }
+    block_sum<1>(k, red_slot, cc);
+    if (n_new > 0xFFFFFFFFull) stop = STOP_RANGE;
+    if (tid == 0) {
+        stg<uint32_t>((uint8_t*)(k.rm + pm) + 4, (uint32_t)n_new);
+        stg<uint32_t>(k.card + pm, (uint32_t)cc[0]);
+    }
+}
+
 // one tree per workgroup
-__global__ __launch_bounds__(TB) void k_tree_insert(TreeDev* trees, const uint8_t* rows, long long row_stride,
-                                                    const uint8_t* bufs, int width, long long n_elems,
-                                                    uint32_t* out_leaf) {
+__global__ __launch_bounds__(TB) void k_tree_insert(TreeDev* trees) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     TreeDev* T = trees + blockIdx.x;
-    Ctx c;
-    c.t = *T;
-    smem_layout(c.t.bf, c.t.RB, &c.s, smem_raw);
-    c.RBc = c.t.RB / 16;
-    c.node_rows = (size_t)c.t.bf + 1;
-    c.red_slot = 0;
-    c.cmp_par = 0;
-    c.bufs = bufs;
-    c.width = width;
+    KC k;
+    k.cent = T->node_cent; k.card = T->node_card; k.link = T->node_link; k.rm = T->node_rm; k.hdr = T->node_hdr;
+    k.scratch = T->scratch_cent; k.cf8 = T->cf8; k.cf16 = T->cf16; k.cf32 = T->cf32;
+    k.bufs = T->bufs; k.width = T->width;
+    k.F = T->F; k.nb = T->nbytes; k.RB = T->RB; k.RBc = k.RB / 16; k.RBS = k.RB + 16;
+    k.bf = (uint32_t)T->bf; k.rows = k.bf + 1;
+    k.crit = T->crit; k.tol_len = T->tol_len; k.thr = T->thr; k.tolerance = T->tolerance; k.tol = T->tol_table;
+    k.use_rc = T->use_root_cache != 0;
+    k.L = (LA unsigned char*)smem_raw;
+    k.o = smem_layout((int)k.bf, k.RB, k.use_rc);
+    const uint8_t* in_rows = T->rows;
+    const long long row_stride = T->row_stride;
+    const long long n_elems = T->n_elems;
+    uint32_t* out_leaf = T->out_leaf;
+    const uint32_t cap_nodes = T->cap_nodes, cap8 = T->cap8, cap16 = T->cap16, cap32 = T->cap32;
+    const bool bufmode = k.bufs != nullptr;
     const int tid = threadIdx.x;
-    const int nb = c.t.nbytes;
-    const uint32_t bf = (uint32_t)c.t.bf;
-    if (tid < C_COUNT) c.s.ctr[tid] = c.t.ctr[tid];
-    if (tid < 8) c.s.stats[tid] = c.t.stats[tid];
+    const int nb = k.nb;
+    const uint32_t bf = k.bf;
+    const bool use_rc = k.use_rc;
+    LA u64* stats = lds<u64>(k.L, k.o.stats);
+    LA uint32_t* bc = lds<uint32_t>(k.L, k.o.bc);
+    LA uint32_t* path_node = lds<uint32_t>(k.L, k.o.path_node);
+    LA uint32_t* path_row = lds<uint32_t>(k.L, k.o.path_row);
+    LA uint32_t* path_len = lds<uint32_t>(k.L, k.o.path_len);
+    LA uint32_t* path_slot = lds<uint32_t>(k.L, k.o.path_slot);
+    LA uint32_t* path_n = lds<uint32_t>(k.L, k.o.path_n);
+    LA u32x4_t* sx = lds<u32x4_t>(k.L, k.o.x);
+    int red_slot = 0, cmp_par = 0;
+    // allocation counters and tree roots: wave-uniform registers, updated identically by every thread
+    uint32_t cN = T->ctr[C_NODES], cI = T->ctr[C_IDS], c8 = T->ctr[C_N8], c16 = T->ctr[C_N16], c32 = T->ctr[C_N32];
+    uint32_t cRoot = T->ctr[C_ROOT], cFirst = T->ctr[C_FIRST_LEAF], cDepth = T->ctr[C_DEPTH];
+    if (tid < 8) stats[tid] = T->stats[tid];
+    for (int ch = tid; ch < k.RBc; ch += TB) sx[ch] = (u32x4_t)(0);  // padding bytes stay zero
     __syncthreads();
+    bool root_dirty = true;  // root length / LDS mirror must be (re)loaded
+    uint32_t root_len = 0, root_leaf = 1;
+    u64 ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    u64 tmark = __builtin_amdgcn_s_memtime();
+#define PHASE(i) do { const u64 _n = __builtin_amdgcn_s_memtime(); ph[i] += _n - tmark; tmark = _n; } while (0)
 
     long long e = 0;
     int stop = STOP_DONE;
@@ -651,229 +835,333 @@ __global__ __launch_bounds__(TB) void k_tree_insert(TreeDev* trees, const uint8_
         __syncthreads();
         // ---- capacity for the worst case of one insertion -------------------------------
         {
-            const uint32_t depth = c.s.ctr[C_DEPTH];
-            const uint32_t need_nodes = depth + 2, need_subs = 2 * (depth + 1) + 1;
+            const uint32_t depth = cDepth;
             if (depth + 2 >= (uint32_t)MAXD) { stop = STOP_DEPTH; break; }
-            if (c.s.ctr[C_NODES] + need_nodes > c.t.cap_nodes) { stop = STOP_NODES; break; }
-            if (c.s.ctr[C_SUBS] + need_subs > c.t.cap_subs) { stop = STOP_SUBS; break; }
-            if (c.s.ctr[C_N8] + 1 > c.t.cap8) { stop = STOP_CF8; break; }
-            if (c.s.ctr[C_N16] + 1 > c.t.cap16) { stop = STOP_CF16; break; }
-            if (c.s.ctr[C_N32] + need_subs > c.t.cap32) { stop = STOP_CF32; break; }
+            if (cN + depth + 2 > cap_nodes) { stop = STOP_NODES; break; }
+            if (c8 + 1 > cap8) { stop = STOP_CF8; break; }
+            if (c16 + 1 > cap16) { stop = STOP_CF16; break; }
+            if (c32 + 2 * (depth + 1) + 1 > cap32) { stop = STOP_CF32; break; }
         }
-        c.elem = e;
+        const uint32_t root = cRoot;
+        if (root_dirty) {
+            if (use_rc) root_mirror_load(k, root);
+            const u32x4_t h = ldg<u32x4_t>(k.hdr + root);
+            root_len = uni(h.x);
+            root_leaf = uni(h.y);
+            root_dirty = false;
+        }
+        Elem el;
+        el.idx = e;
         // ---- element: packed centroid into LDS, n, moments ------------------------------
-        for (int ch = tid; ch < c.RBc; ch += TB) c.s.x[ch] = make_uint4(0, 0, 0, 0);
-        __syncthreads();
-        if (bufs == nullptr) {
-            const uint8_t* row = rows + e * row_stride;
+        if (!bufmode) {
+            const uint8_t* row = in_rows + e * row_stride;
             if ((((uintptr_t)row) & 15) == 0 && (nb & 15) == 0) {
-                for (int ch = tid; ch < c.RBc; ch += TB) c.s.x[ch] = reinterpret_cast<const uint4*>(row)[ch];
+                for (int ch = tid; ch < k.RBc; ch += TB) sx[ch] = ldg<u32x4_t>(row + (size_t)ch * 16);
             } else {
-                for (int b = tid; b < nb; b += TB) reinterpret_cast<uint8_t*>(c.s.x)[b] = row[b];
+                for (int b = tid; b < nb; b += TB) lds<uint8_t>(k.L, k.o.x)[b] = ldg<uint8_t>(row + b);
             }
-            c.nS = 1;
+            el.nS = 1;
             __syncthreads();
-            c.pcx = lds_vec_popcount(c, c.s.x);
-            c.s1S = c.pcx;
-            c.s2S = c.pcx;
+            el.pcx = lds_vec_popcount(k, k.o.x);
+            el.s1S = el.pcx;
+            el.s2S = el.pcx;
         } else {
-            unsigned long long nraw;
-            const size_t ncol = (size_t)e * ((size_t)c.t.F + 1) + (size_t)c.t.F;
-            switch (width) {
-                case 1: nraw = bufs[ncol]; break;
-                case 2: nraw = reinterpret_cast<const uint16_t*>(bufs)[ncol]; break;
-                case 4: nraw = reinterpret_cast<const uint32_t*>(bufs)[ncol]; break;
-                default: nraw = reinterpret_cast<const unsigned long long*>(bufs)[ncol]; break;
+            u64 nraw;
+            const size_t ncol = (size_t)e * ((size_t)k.F + 1) + (size_t)k.F;
+            switch (k.width) {
+                case 1: nraw = ldg<uint8_t>(k.bufs + ncol); break;
+                case 2: nraw = ldg<uint16_t>(k.bufs + 2 * ncol); break;
+                case 4: nraw = ldg<uint32_t>(k.bufs + 4 * ncol); break;
+                default: nraw = ldg<u64>(k.bufs + 8 * ncol); break;
             }
+            nraw = uni64(nraw);
             if (nraw > 0xFFFFFFFFull) { stop = STOP_RANGE; break; }
-            c.nS = (uint32_t)nraw;
-            unsigned long long a = 0, q = 0;
+            el.nS = (uint32_t)nraw;
+            el.pcx = 0; el.s1S = 0; el.s2S = 0;
+            u64 acc[2] = {0, 0};
             for (int b = tid; b < nb; b += TB) {
                 uint32_t v[8];
-                elem_cols(c, b, v);
+                elem_cols(k, el, b, v);
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    a += v[k];
-                    q += (unsigned long long)v[k] * v[k];
+                for (int q = 0; q < 8; ++q) {
+                    acc[0] += v[q];
+                    acc[1] += (u64)v[q] * v[q];
                 }
-                reinterpret_cast<uint8_t*>(c.s.x)[b] = (uint8_t)centroid_byte(v, c.nS);
+                lds<uint8_t>(k.L, k.o.x)[b] = (uint8_t)centroid_byte(v, el.nS);
             }
-            block_sum2(c, a, q);  // barrier: s.x complete
-            c.s1S = a;
-            c.s2S = q;
-            c.pcx = lds_vec_popcount(c, c.s.x);
+            block_sum<2>(k, red_slot, acc);  // barrier: x complete
+            el.s1S = acc[0];
+            el.s2S = acc[1];
+            el.pcx = lds_vec_popcount(k, k.o.x);
         }
+        PHASE(0);
 
-        uint32_t out_id;
+        uint32_t out_id = NONE;
         bool overflow = false;
         int D = 0;  // leaf level index
-        const uint32_t root = c.s.ctr[C_ROOT];
-        uint32_t len = c.t.node_len[root];
-        if (len == 0) {
-            // ---- very first element of an empty tree: becomes row 0 of the root leaf -----
-            const uint32_t tier = tier_for(c.nS);
-            const uint32_t s = c.s.ctr[C_SUBS];
-            const uint32_t slot = c.s.ctr[tier == 0 ? C_N8 : (tier == 1 ? C_N16 : C_N32)];
-            const uint32_t slotw = (tier << 30) | slot;
-            __syncthreads();
+        if (root_len == 0) {
+            // ---- very first element of an empty tree: row 0 of the root leaf -------------
+            const uint32_t tier = tier_for(el.nS);
+            const uint32_t s = cI++;
+            const uint32_t slotw = (tier << 30) | (tier == 0 ? c8++ : (tier == 1 ? c16++ : c32++));
             if (tid == 0) {
-                c.s.ctr[C_SUBS]++;
-                c.s.ctr[tier == 0 ? C_N8 : (tier == 1 ? C_N16 : C_N32)]++;
-                c.t.sub_n[s] = c.nS;
-                c.t.sub_s1[s] = c.s1S;
-                c.t.sub_s2[s] = c.s2S;
-                c.t.sub_slot[s] = slotw;
-                c.t.node_len[root] = 1;
-                c.s.stats[3]++;
+                stg<uint32_t>(k.hdr + root, 1u);
+                stats[3]++;
             }
             for (int b = tid; b < nb; b += TB) {
                 uint32_t v[8];
-                elem_cols(c, b, v);
-                cf_store8(c, slotw, b, v);
+                elem_cols(k, el, b, v);
+                cf_store8(k, slotw, b, v);
             }
-            node_put_row(c, root, 0, c.s.x, c.pcx, s, NONE);
+            node_put_row(k, root, 0, k.o.x, el.pcx, slotw, s, el.nS, slotw, el.s1S, el.s2S);
             out_id = s;
+            root_dirty = true;
         } else {
             // ---- greedy descent (bitbirch.py:305-357) ---------------------------------
-            uint32_t nd = root, j, child, sub;
+            uint32_t nd = root, j = 0, link = NONE, len = root_len, leaf = root_leaf;
             int depth = 0;
+            u32x4_t rm0 = (u32x4_t)(0), rm1 = (u32x4_t)(0);  // RowMeta of the chosen row
+            uint32_t tslot[MAXFAST], tn[MAXFAST];             // ancestors' CF slot / n_samples (uniform)
+#pragma unroll
+            for (int q = 0; q < MAXFAST; ++q) { tslot[q] = 0; tn[q] = 0; }
+            bool bad = false;
             while (true) {
-                node_compare(c, nd, len, c.s.x, c.pcx, 0, nullptr, nullptr, true);
-                j = pick_best(c, len, 0);
-                child = c.s.child[(size_t)c.cmp_par * c.node_rows + j];
-                sub = c.s.sub[(size_t)c.cmp_par * c.node_rows + j];
+                Cand best;
+                if (depth == 0 && use_rc) {
+                    best = node_best<true, false>(k, cmp_par, nd, (int)root_len, k.o.x, el.pcx, false, false, false, nullptr, nullptr);
+                } else if (depth == 0) {
+                    best = node_best<false, false>(k, cmp_par, nd, (int)root_len, k.o.x, el.pcx, false, false, true, nullptr, nullptr);
+                } else {
+                    best = node_best<false, false>(k, cmp_par, nd, -1, k.o.x, el.pcx, false, false, true, &len, &leaf);
+                }
+                j = best.r;
+                if (depth == 0) PHASE(6); else PHASE(7);
+                link = (depth == 0 && use_rc) ? uni(lds<uint32_t>(k.L, k.o.rc_link)[j])
+                                              : uni(lds<uint32_t>(k.L, k.o.link)[cmp_par * k.rows + j]);
+                if (depth > 0) {  // the previous level's RowMeta has arrived by now
+                    const uint32_t ps = uni(rm0.z), pn = uni(rm0.y);
+#pragma unroll
+                    for (int q = 0; q < MAXFAST; ++q)
+                        if (depth - 1 == q) { tslot[q] = ps; tn[q] = pn; }
+                    if (tid == 0) {
+                        path_slot[depth - 1] = ps;
+                        path_n[depth - 1] = pn;
+                    }
+                }
                 if (tid == 0) {
-                    c.s.path_node[depth] = nd;
-                    c.s.path_row[depth] = j;
-                    c.s.path_sub[depth] = sub;
-                    c.s.path_len[depth] = len;
-                    c.s.stats[0]++;
-                    c.s.stats[1] += len;
+                    path_node[depth] = nd;
+                    path_row[depth] = j;
+                    path_len[depth] = len;
+                    stats[0]++;
+                    stats[1] += len;
                 }
-                if (child == NONE) break;
-                if (depth + 2 >= MAXD || child >= c.t.cap_nodes) {  // corrupt or too deep: never spin
-                    stop = STOP_DEPTH;
-                    break;
+                {
+                    const uint8_t* rmp = (const uint8_t*)(k.rm + (size_t)nd * k.rows + j);
+                    rm0 = ldg<u32x4_t>(rmp);
+                    rm1 = ldg<u32x4_t>(rmp + 16);
                 }
-                nd = child;
-                len = c.t.node_len[nd];
+                if (leaf) break;
+                if (depth + 2 >= MAXD || link >= cap_nodes) { bad = true; break; }  // never spin on corruption
+                nd = link;
                 depth++;
             }
-            if (stop != STOP_DONE) break;
+            if (bad) { stop = STOP_DEPTH; break; }
+            PHASE(1);
             D = depth;
-            if ((unsigned long long)(D + 1) > c.s.stats[6] && tid == 0) c.s.stats[6] = (unsigned long long)(D + 1);
-            const uint32_t leafnode = nd, jl = j, Tsub = sub, leaflen = len;
-            // ---- leaf merge test (merge_subcluster, bitbirch.py:507-526) ----------------
-            const uint32_t slotT = c.t.sub_slot[Tsub];
-            const unsigned long long nT = c.t.sub_n[Tsub];
-            const unsigned long long s1T = c.t.sub_s1[Tsub], s2T = c.t.sub_s2[Tsub];
-            unsigned long long dot = 0, zz = 0;
-            for (int b = tid; b < nb; b += TB) {
-                uint32_t v[8], x8[8];
-                cf_load8(c, slotT, b, v);
-                elem_cols(c, b, x8);
-#pragma unroll
-                for (int k = 0; k < 8; ++k) dot += (unsigned long long)v[k] * x8[k];
-            }
-            block_sum2(c, dot, zz);
-            const unsigned long long new_n = nT + c.nS;
+            if (tid == 0 && (u64)(D + 1) > stats[6]) stats[6] = (u64)(D + 1);
+            const uint32_t leafnode = nd, jl = j, leaflen = len;
+            const uint32_t slotT = link;  // leaf row: link = CF slot word
+            const uint32_t Tsub = uni(rm0.x);
+            const u64 nT = uni(rm0.y);
+            const u64 s1T = ((u64)uni(rm1.y) << 32) | uni(rm1.x);
+            const u64 s2T = ((u64)uni(rm1.w) << 32) | uni(rm1.z);
+            const u64 new_n = nT + el.nS;
             if (new_n > 0xFFFFFFFFull) { stop = STOP_RANGE; break; }
-            const unsigned long long s1n = s1T + c.s1S;
-            const unsigned long long s2n = s2T + 2ull * dot + c.s2S;
-            const bool accept = merge_accept(c, slotT, nT, s1T, s2T, new_n, s1n, s2n);
-            if (accept) {
-                // replace_n_samples_and_linear_sum (bitbirch.py:476-484)
-                const uint32_t old_tier = slotT >> 30, new_tier = tier_for(new_n) > old_tier ? tier_for(new_n) : old_tier;
-                uint32_t slotN = slotT;
-                if (new_tier != old_tier) {
-                    const int which = new_tier == 1 ? C_N16 : C_N32;
-                    slotN = (new_tier << 30) | c.s.ctr[which];
-                    __syncthreads();
-                    if (tid == 0) c.s.ctr[which]++;
+            // ---- one fused pass: leaf dot product, speculative merged CF + centroid, and
+            //      every ancestor's CF += element with its new centroid; one reduction ----
+            const bool fast = nb <= TB;  // one byte-group (8 features) per thread
+            u64 red[NRED];
+#pragma unroll
+            for (int i = 0; i < NRED; ++i) red[i] = 0;
+            uint32_t xs[8], vL[8], vT[MAXFAST][8], byteL = 0, byteT[MAXFAST];
+            const int b0 = tid;
+            const bool act = fast && b0 < nb;
+            const int DT = D < MAXFAST ? D : MAXFAST;  // ancestors handled here
+#pragma unroll
+            for (int q = 0; q < MAXFAST; ++q) byteT[q] = 0;
+            if (fast) {
+                if (act) {
+                    elem_cols(k, el, b0, xs);
+                    cf_load8(k, slotT, b0, vL);
+#pragma unroll
+                    for (int q = 0; q < MAXFAST; ++q)
+                        if (q < DT) cf32_load8(k, tslot[q], b0, vT[q]);
+                    uint32_t dot32 = 0;
+                    u64 dot = 0;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        dot += (u64)vL[q] * xs[q];
+                        dot32 += vL[q] * xs[q];
+                        vL[q] += xs[q];
+                    }
+                    red[0] = bufmode ? dot : (u64)dot32;  // fingerprint bits are 0/1: no overflow in 32 bits
+                    byteL = centroid_byte(vL, new_n);
+                    red[1] = __popc(byteL);
+#pragma unroll
+                    for (int q = 0; q < MAXFAST; ++q) {
+                        if (q < DT) {
+#pragma unroll
+                            for (int z = 0; z < 8; ++z) vT[q][z] += xs[z];
+                            byteT[q] = centroid_byte(vT[q], (u64)tn[q] + el.nS);
+                            red[2 + q] = __popc(byteT[q]);
+                        }
+                    }
                 }
-                unsigned long long card = 0, z2 = 0;
-                uint8_t* crow = c.t.node_cent + ((size_t)leafnode * c.node_rows + jl) * (size_t)c.t.RB;
+            } else {
                 for (int b = tid; b < nb; b += TB) {
                     uint32_t v[8], x8[8];
-                    cf_load8(c, slotT, b, v);
-                    elem_cols(c, b, x8);
+                    cf_load8(k, slotT, b, v);
+                    elem_cols(k, el, b, x8);
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) v[k] += x8[k];
-                    cf_store8(c, slotN, b, v);
-                    const uint32_t byte = centroid_byte(v, new_n);
-                    crow[b] = (uint8_t)byte;
-                    card += __popc(byte);
+                    for (int q = 0; q < 8; ++q) red[0] += (u64)v[q] * x8[q];
                 }
-                block_sum2(c, card, z2);
+            }
+            PHASE(2);
+            block_sum<NRED>(k, red_slot, red);
+            PHASE(3);
+            const u64 s1n = s1T + el.s1S;
+            const u64 s2n = s2T + 2ull * red[0] + el.s2S;
+            const bool accept = merge_accept(k, el, red_slot, slotT, nT, s1T, s2T, new_n, s1n, s2n);
+            const size_t leafm = (size_t)leafnode * k.rows;
+            if (accept) {
+                // replace_n_samples_and_linear_sum (bitbirch.py:476-484)
+                const uint32_t old_tier = slotT >> 30;
+                const uint32_t new_tier = tier_for(new_n) > old_tier ? tier_for(new_n) : old_tier;
+                uint32_t slotN = slotT;
+                if (new_tier != old_tier) {
+                    slotN = (new_tier << 30) | (new_tier == 1 ? c16++ : c32++);
+                }
+                uint8_t* crow = k.cent + (leafm + jl) * (size_t)k.RB;
+                u64 card = red[1];
+                if (fast) {
+                    if (act) {
+                        cf_store8(k, slotN, b0, vL);
+                        stg<uint8_t>(crow + b0, (uint8_t)byteL);
+                    }
+                } else {
+                    u64 cc[1] = {0};
+                    for (int b = tid; b < nb; b += TB) {
+                        uint32_t v[8], x8[8];
+                        cf_load8(k, slotT, b, v);
+                        elem_cols(k, el, b, x8);
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) v[q] += x8[q];
+                        cf_store8(k, slotN, b, v);
+                        const uint32_t byte = centroid_byte(v, new_n);
+                        stg<uint8_t>(crow + b, (uint8_t)byte);
+                        cc[0] += __popc(byte);
+                    }
+                    block_sum<1>(k, red_slot, cc);
+                    card = cc[0];
+                }
                 if (tid == 0) {
-                    c.t.sub_n[Tsub] = (uint32_t)new_n;
-                    c.t.sub_s1[Tsub] = s1n;
-                    c.t.sub_s2[Tsub] = s2n;
-                    c.t.sub_slot[Tsub] = slotN;
-                    c.t.node_card[(size_t)leafnode * c.node_rows + jl] = (uint32_t)card;
-                    c.s.stats[2]++;
+                    u32x4_t a, b;
+                    a.x = Tsub; a.y = (uint32_t)new_n; a.z = slotN; a.w = 0;
+                    b.x = (uint32_t)s1n; b.y = (uint32_t)(s1n >> 32); b.z = (uint32_t)s2n; b.w = (uint32_t)(s2n >> 32);
+                    stg<u32x4_t>((uint8_t*)(k.rm + leafm + jl), a);
+                    stg<u32x4_t>((uint8_t*)(k.rm + leafm + jl) + 16, b);
+                    stg<uint32_t>(k.card + leafm + jl, (uint32_t)card);
+                    if (slotN != slotT) stg<uint32_t>(k.link + leafm + jl, slotN);
+                    stats[2]++;
                 }
                 out_id = Tsub;
             } else {
                 // append_subcluster (bitbirch.py:284-287): new leaf BitFeature
-                const uint32_t tier = tier_for(c.nS);
-                const int which = tier == 0 ? C_N8 : (tier == 1 ? C_N16 : C_N32);
-                const uint32_t s = c.s.ctr[C_SUBS];
-                const uint32_t slotw = (tier << 30) | c.s.ctr[which];
-                __syncthreads();
+                const uint32_t tier = tier_for(el.nS);
+                const uint32_t s = cI++;
+                const uint32_t slotw = (tier << 30) | (tier == 0 ? c8++ : (tier == 1 ? c16++ : c32++));
                 if (tid == 0) {
-                    c.s.ctr[C_SUBS]++;
-                    c.s.ctr[which]++;
-                    c.t.sub_n[s] = c.nS;
-                    c.t.sub_s1[s] = c.s1S;
-                    c.t.sub_s2[s] = c.s2S;
-                    c.t.sub_slot[s] = slotw;
-                    c.t.node_len[leafnode] = leaflen + 1;
-                    c.s.stats[3]++;
+                    stg<uint32_t>(k.hdr + leafnode, leaflen + 1);
+                    stats[3]++;
                 }
-                for (int b = tid; b < nb; b += TB) {
-                    uint32_t v[8];
-                    elem_cols(c, b, v);
-                    cf_store8(c, slotw, b, v);
+                if (fast) {
+                    if (act) cf_store8(k, slotw, b0, xs);
+                } else {
+                    for (int b = tid; b < nb; b += TB) {
+                        uint32_t v[8];
+                        elem_cols(k, el, b, v);
+                        cf_store8(k, slotw, b, v);
+                    }
                 }
-                node_put_row(c, leafnode, leaflen, c.s.x, c.pcx, s, NONE);
+                node_put_row(k, leafnode, leaflen, k.o.x, el.pcx, slotw, s, el.nS, slotw, el.s1S, el.s2S);
                 out_id = s;
                 overflow = leaflen + 1 > bf;
             }
+            if (D == 0) root_dirty = true;  // the root itself is the leaf that changed
+            // ---- ancestors (closest_subcluster.update, bitbirch.py:352-357) ----------------
+            if (!overflow) {
+                if (fast) {
+#pragma unroll
+                    for (int q = 0; q < MAXFAST; ++q) {
+                        if (q < DT) {
+                            const uint32_t P = uni(path_node[q]), jp = uni(path_row[q]);
+                            const size_t pm = (size_t)P * k.rows + jp;
+                            const u64 n_new = (u64)tn[q] + el.nS;
+                            if (n_new > 0xFFFFFFFFull) stop = STOP_RANGE;
+                            if (act) {
+                                cf_store8(k, tslot[q], b0, vT[q]);
+                                stg<uint8_t>(k.cent + pm * (size_t)k.RB + b0, (uint8_t)byteT[q]);
+                                if (q == 0 && use_rc) *(LA uint8_t*)(k.L + k.o.rc_cent + jp * k.RBS + b0) = (uint8_t)byteT[q];
+                            }
+                            if (tid == 0) {
+                                stg<uint32_t>((uint8_t*)(k.rm + pm) + 4, (uint32_t)n_new);
+                                stg<uint32_t>(k.card + pm, (uint32_t)red[2 + q]);
+                                if (q == 0 && use_rc) lds<uint32_t>(k.L, k.o.rc_card)[jp] = (uint32_t)red[2 + q];
+                            }
+                        }
+                    }
+                }
+                for (int lv = fast ? DT : 0; lv < D; ++lv) {  // deep trees / wide rows: one level at a time
+                    update_tracker_slow(k, el, red_slot, lv, stop);
+                    if (lv == 0) root_dirty = true;
+                }
+            }
         }
-        __syncthreads();
-        // ---- upward pass -----------------------------------------------------------------
-        int upd_levels = D;  // tracking BitFeatures at levels [0, upd_levels) get CF += element
+        PHASE(4);
+        // ---- overflow: split upward (bitbirch.py:339-350, :778-782) ------------------------
         if (overflow) {
+            __syncthreads();
             int lvl = D;
+            int upd_levels = 0;
+            bool range_bad = false;
             while (true) {
-                const uint32_t nd = c.s.path_node[lvl];
-                split_node(c, nd);
-                const uint32_t node1 = c.s.bc[0], A = c.s.bc[1], B = c.s.bc[2], cardA = c.s.bc[3], cardB = c.s.bc[4];
+                const uint32_t nd = uni(path_node[lvl]);
+                split_node(k, red_slot, cmp_par, nd, cN, c32, cFirst);
+                const uint32_t node1 = uni(bc[0]), cardA = uni(bc[3]), cardB = uni(bc[4]);
+                const uint32_t nA = uni(bc[7]), nB = uni(bc[8]);
+                const uint32_t slotA = (2u << 30) | uni(bc[9]), slotB = (2u << 30) | uni(bc[10]);
+                if (uni(bc[11])) { range_bad = true; break; }
                 if (lvl == 0) {
-                    // root split: new root holding the two tracking BitFeatures (bitbirch.py:778-782)
-                    const uint32_t nr = c.s.ctr[C_NODES];
-                    __syncthreads();
-                    node_put_row(c, nr, 0, c.s.cA, cardA, A, node1);
-                    node_put_row(c, nr, 1, c.s.cB, cardB, B, nd);
+                    // root split: new root holding the two tracking BitFeatures
+                    const uint32_t nr = cN++;
+                    cRoot = nr;
+                    cDepth++;
+                    node_put_row(k, nr, 0, k.o.cA, cardA, node1, NONE, nA, slotA, 0, 0);
+                    node_put_row(k, nr, 1, k.o.cB, cardB, nd, NONE, nB, slotB, 0, 0);
                     if (tid == 0) {
-                        c.s.ctr[C_NODES]++;
-                        c.t.node_len[nr] = 2;
-                        c.t.node_leaf[nr] = 0;
-                        c.t.node_prev[nr] = NONE;
-                        c.t.node_next[nr] = NONE;
-                        c.s.ctr[C_ROOT] = nr;
-                        c.s.ctr[C_DEPTH]++;
-                        c.s.stats[5]++;
+                        u32x4_t h;
+                        h.x = 2; h.y = 0; h.z = NONE; h.w = NONE;
+                        stg<u32x4_t>(k.hdr + nr, h);
+                        stats[5]++;
                     }
                     upd_levels = 0;
                     break;
                 }
                 // update_split_subclusters (bitbirch.py:289-303)
-                const uint32_t P = c.s.path_node[lvl - 1], jp = c.s.path_row[lvl - 1], lenP = c.s.path_len[lvl - 1];
-                node_put_row(c, P, jp, c.s.cA, cardA, A, node1);
-                node_put_row(c, P, lenP, c.s.cB, cardB, B, nd);
-                if (tid == 0) c.t.node_len[P] = lenP + 1;
+                const uint32_t P = uni(path_node[lvl - 1]), jp = uni(path_row[lvl - 1]), lenP = uni(path_len[lvl - 1]);
+                node_put_row(k, P, jp, k.o.cA, cardA, node1, NONE, nA, slotA, 0, 0);
+                node_put_row(k, P, lenP, k.o.cB, cardB, nd, NONE, nB, slotB, 0, 0);
+                if (tid == 0) stg<uint32_t>(k.hdr + P, lenP + 1);
                 __syncthreads();
                 if (lenP + 1 > bf) {
                     lvl--;
@@ -882,43 +1170,27 @@ __global__ __launch_bounds__(TB) void k_tree_insert(TreeDev* trees, const uint8_
                 upd_levels = lvl - 1;
                 break;
             }
+            if (range_bad) { stop = STOP_RANGE; break; }
             __syncthreads();
+            root_dirty = true;
+            for (int lv = 0; lv < upd_levels; ++lv) update_tracker_slow(k, el, red_slot, lv, stop);
         }
-        // closest_subcluster.update(subcluster) for the untouched ancestors (bitbirch.py:352-357)
-        for (int k = 0; k < upd_levels; ++k) {
-            const uint32_t t = c.s.path_sub[k], P = c.s.path_node[k], jp = c.s.path_row[k];
-            const uint32_t slotw = c.t.sub_slot[t];
-            const unsigned long long n_new = (unsigned long long)c.t.sub_n[t] + c.nS;
-            if (n_new > 0xFFFFFFFFull) { stop = STOP_RANGE; break; }
-            unsigned long long card = 0, z2 = 0;
-            uint8_t* crow = c.t.node_cent + ((size_t)P * c.node_rows + jp) * (size_t)c.t.RB;
-            for (int b = tid; b < nb; b += TB) {
-                uint32_t v[8], x8[8];
-                cf_load8(c, slotw, b, v);
-                elem_cols(c, b, x8);
-#pragma unroll
-                for (int kk = 0; kk < 8; ++kk) v[kk] += x8[kk];
-                cf_store8(c, slotw, b, v);
-                const uint32_t byte = centroid_byte(v, n_new);
-                crow[b] = (uint8_t)byte;
-                card += __popc(byte);
-            }
-            block_sum2(c, card, z2);
-            if (tid == 0) {
-                c.t.sub_n[t] = (uint32_t)n_new;
-                c.t.node_card[(size_t)P * c.node_rows + jp] = (uint32_t)card;
-            }
-        }
+        PHASE(5);
         if (stop != STOP_DONE) break;
-        if (tid == 0 && out_leaf) out_leaf[e] = out_id;
+        if (tid == 0 && out_leaf) stg<uint32_t>(out_leaf + e, out_id);
     }
     __syncthreads();
-    if (tid < C_COUNT) T->ctr[tid] = c.s.ctr[tid];
-    if (tid < 8) T->stats[tid] = c.s.stats[tid];
+    if (tid == 0) {
+        T->ctr[C_NODES] = cN; T->ctr[C_IDS] = cI; T->ctr[C_N8] = c8; T->ctr[C_N16] = c16; T->ctr[C_N32] = c32;
+        T->ctr[C_ROOT] = cRoot; T->ctr[C_FIRST_LEAF] = cFirst; T->ctr[C_DEPTH] = cDepth;
+    }
+    if (tid < 8) T->stats[tid] = stats[tid];
     if (tid == 0) {
         T->processed = e;
         T->stop_reason = stop;
+        for (int i = 0; i < 8; ++i) T->phase[i] += ph[i];
     }
+#undef PHASE
 }
 
 // ---- extraction ---------------------------------------------------------------------------
@@ -932,18 +1204,18 @@ __global__ __launch_bounds__(256) void k_gather_leaves(TreeDev* Tp, const uint32
     if (i >= m) return;
     const size_t rows = (size_t)t.bf + 1;
     const uint32_t nd = nodes[i], r = rowsidx[i];
-    const uint32_t sub = t.node_sub[(size_t)nd * rows + r];
-    const uint32_t n = t.sub_n[sub];
+    const RowMeta rm = t.node_rm[(size_t)nd * rows + r];
+    const uint32_t n = rm.n;
     if (threadIdx.x == 0) {
         if (out_n) out_n[i] = n;
-        if (out_ids) out_ids[i] = sub;
+        if (out_ids) out_ids[i] = rm.sub;
     }
     if (out_cent) {
         const uint8_t* src = t.node_cent + ((size_t)nd * rows + r) * (size_t)t.RB;
         for (int b = threadIdx.x; b < t.nbytes; b += blockDim.x) out_cent[(size_t)i * t.nbytes + b] = src[b];
     }
     if (out_bufs) {
-        const uint32_t slotw = t.sub_slot[sub];
+        const uint32_t slotw = rm.slot;
         const uint32_t tier = slotw >> 30;
         const size_t base = (size_t)(slotw & 0x3FFFFFFFu) * (size_t)t.F;
         const size_t cols = (size_t)t.F + (ls_only ? 0 : 1);
@@ -999,28 +1271,11 @@ int grow_nodes(bbh_tree* t, uint32_t want) {
     const size_t rows = (size_t)h.bf + 1;
     const size_t oc = h.cap_nodes, nc = want;
     BB_TRY(grow_pool(h.node_cent, oc * rows * h.RB, nc * rows * h.RB));
-    BB_TRY(grow_pool(h.node_sub, oc * rows, nc * rows));
-    BB_TRY(grow_pool(h.node_child, oc * rows, nc * rows));
     BB_TRY(grow_pool(h.node_card, oc * rows, nc * rows));
-    BB_TRY(grow_pool(h.node_len, oc, nc));
-    BB_TRY(grow_pool(h.node_prev, oc, nc));
-    BB_TRY(grow_pool(h.node_next, oc, nc));
-    BB_TRY(grow_pool(h.node_leaf, oc, nc));
-    // new nodes must start empty
-    BB_HIP(hipMemset(h.node_len + oc, 0, (nc - oc) * sizeof(uint32_t)));
+    BB_TRY(grow_pool(h.node_link, oc * rows, nc * rows));
+    BB_TRY(grow_pool(h.node_rm, oc * rows, nc * rows));
+    BB_TRY(grow_pool(h.node_hdr, oc, nc));
     h.cap_nodes = (uint32_t)nc;
-    return BBH_OK;
-}
-
-int grow_subs(bbh_tree* t, uint32_t want) {
-    TreeDev& h = t->h;
-    if (want <= h.cap_subs) return BBH_OK;
-    const size_t oc = h.cap_subs, nc = want;
-    BB_TRY(grow_pool(h.sub_n, oc, nc));
-    BB_TRY(grow_pool(h.sub_s1, oc, nc));
-    BB_TRY(grow_pool(h.sub_s2, oc, nc));
-    BB_TRY(grow_pool(h.sub_slot, oc, nc));
-    h.cap_subs = (uint32_t)nc;
     return BBH_OK;
 }
 
@@ -1042,14 +1297,12 @@ int grow_cf(bbh_tree* t, int tier, uint32_t want) {
 
 void free_pools(bbh_tree* t) {
     TreeDev& h = t->h;
-    void* ptrs[] = {h.node_cent, h.node_sub, h.node_child, h.node_card, h.node_len, h.node_prev, h.node_next,
-                    h.node_leaf, h.scratch_cent, h.sub_n, h.sub_s1, h.sub_s2, h.sub_slot, h.cf8, h.cf16, h.cf32};
+    void* ptrs[] = {h.node_cent, h.node_card, h.node_link, h.node_rm, h.node_hdr, h.scratch_cent, h.cf8, h.cf16, h.cf32};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
-    h.node_cent = nullptr; h.node_sub = h.node_child = h.node_card = h.node_len = h.node_prev = h.node_next = nullptr;
-    h.node_leaf = nullptr; h.scratch_cent = nullptr; h.sub_n = nullptr; h.sub_s1 = h.sub_s2 = nullptr;
-    h.sub_slot = nullptr; h.cf8 = nullptr; h.cf16 = nullptr; h.cf32 = nullptr;
-    h.cap_nodes = h.cap_subs = h.cap8 = h.cap16 = h.cap32 = 0;
+    h.node_cent = nullptr; h.node_card = nullptr; h.node_link = nullptr; h.node_rm = nullptr; h.node_hdr = nullptr;
+    h.scratch_cent = nullptr; h.cf8 = nullptr; h.cf16 = nullptr; h.cf32 = nullptr;
+    h.cap_nodes = h.cap8 = h.cap16 = h.cap32 = 0;
 }
 
 // an empty tree: one empty leaf root (bitbirch.py:880-884)
@@ -1057,20 +1310,18 @@ int init_empty(bbh_tree* t) {
     TreeDev& h = t->h;
     std::memset(h.ctr, 0, sizeof(h.ctr));
     BB_TRY(grow_nodes(t, std::max<uint32_t>(h.cap_nodes, 64)));
-    BB_TRY(grow_subs(t, std::max<uint32_t>(h.cap_subs, 1024)));
     BB_TRY(grow_cf(t, 0, std::max<uint32_t>(h.cap8, 1024)));
     BB_TRY(grow_cf(t, 1, std::max<uint32_t>(h.cap16, 64)));
     BB_TRY(grow_cf(t, 2, std::max<uint32_t>(h.cap32, 256)));
-    const uint32_t zero = 0, one = 1, none = NONE;
-    BB_HIP(hipMemcpy(h.node_len, &zero, 4, hipMemcpyHostToDevice));
-    BB_HIP(hipMemcpy(h.node_leaf, &one, 4, hipMemcpyHostToDevice));
-    BB_HIP(hipMemcpy(h.node_prev, &none, 4, hipMemcpyHostToDevice));
-    BB_HIP(hipMemcpy(h.node_next, &none, 4, hipMemcpyHostToDevice));
+    NodeHdr root;
+    root.len = 0; root.leaf = 1; root.prev = NONE; root.next = NONE;
+    BB_HIP(hipMemcpy(h.node_hdr, &root, sizeof(root), hipMemcpyHostToDevice));
     h.ctr[C_NODES] = 1;
     h.ctr[C_ROOT] = 0;
     h.ctr[C_FIRST_LEAF] = 0;
     h.ctr[C_DEPTH] = 1;
     std::memset(h.stats, 0, sizeof(h.stats));
+    std::memset(h.phase, 0, sizeof(h.phase));
     h.stats[5] = 1;
     t->chain_valid = false;
     return BBH_OK;
@@ -1098,7 +1349,10 @@ int configure(bbh_tree* t, int32_t bf, int32_t n_features) {
     h.F = n_features;
     h.nbytes = n_features / 8;
     h.RB = (h.nbytes + 15) / 16 * 16;
-    t->lds = smem_layout(bf, h.RB, nullptr, nullptr);
+    // the LDS mirror of the root is used whenever it fits comfortably
+    const size_t with_rc = smem_layout(bf, h.RB, true).total;
+    h.use_root_cache = with_rc <= 100 * 1024 ? 1 : 0;
+    t->lds = smem_layout(bf, h.RB, h.use_root_cache != 0).total;
     if (h.scratch_cent) (void)hipFree(h.scratch_cent);
     h.scratch_cent = nullptr;
     BB_HIP(hipMalloc(&h.scratch_cent, ((size_t)bf + 1) * h.RB));
@@ -1115,14 +1369,16 @@ int run_insert(bbh_tree* t, const uint8_t* rows_dev, int64_t row_stride, const u
     int64_t done = 0;
     int stalls = 0;
     while (done < n) {
+        h.rows = rows_dev ? rows_dev + done * row_stride : nullptr;
+        h.row_stride = row_stride;
+        h.bufs = bufs_dev ? bufs_dev + (size_t)done * ((size_t)h.F + 1) * width : nullptr;
+        h.width = width;
+        h.n_elems = n - done;
+        h.out_leaf = out_leaf_dev ? out_leaf_dev + done : nullptr;
         BB_HIP(hipMemcpyAsync(t->d, &h, sizeof(TreeDev), hipMemcpyHostToDevice, s));
-        const int64_t chunk = n - done;
         {
             bb::ProfScope ps("tree_insert", s);
-            hipLaunchKernelGGL(k_tree_insert, dim3(1), dim3(TB), t->lds, s, t->d,
-                               rows_dev ? rows_dev + done * row_stride : nullptr, (long long)row_stride,
-                               bufs_dev ? bufs_dev + (size_t)done * ((size_t)h.F + 1) * width : nullptr, width,
-                               (long long)chunk, out_leaf_dev ? out_leaf_dev + done : nullptr);
+            hipLaunchKernelGGL(k_tree_insert, dim3(1), dim3(TB), t->lds, s, t->d);
             BB_HIP(hipGetLastError());
         }
         TreeDev back;
@@ -1130,6 +1386,7 @@ int run_insert(bbh_tree* t, const uint8_t* rows_dev, int64_t row_stride, const u
         BB_HIP(hipStreamSynchronize(s));
         std::memcpy(h.ctr, back.ctr, sizeof(h.ctr));
         std::memcpy(h.stats, back.stats, sizeof(h.stats));
+        std::memcpy(h.phase, back.phase, sizeof(h.phase));
         done += back.processed;
         stalls = back.processed == 0 ? stalls + 1 : 0;
         if (stalls > 3) return bb::fail(BBH_ERR_CAPACITY, "tree engine made no progress (stop reason %d)", back.stop_reason);
@@ -1144,11 +1401,10 @@ int run_insert(bbh_tree* t, const uint8_t* rows_dev, int64_t row_stride, const u
         switch (back.stop_reason) {
             case STOP_DONE: break;
             case STOP_NODES: BB_TRY(grow_nodes(t, more(h.ctr[C_NODES], h.cap_nodes, 1))); break;
-            case STOP_SUBS: BB_TRY(grow_subs(t, more(h.ctr[C_SUBS], h.cap_subs, 4))); break;
             case STOP_CF8: BB_TRY(grow_cf(t, 0, more(h.ctr[C_N8], h.cap8, 4))); break;
             case STOP_CF16: BB_TRY(grow_cf(t, 1, more(h.ctr[C_N16], h.cap16, 1))); break;
             case STOP_CF32: BB_TRY(grow_cf(t, 2, more(h.ctr[C_N32], h.cap32, 1))); break;
-            case STOP_DEPTH: return bb::fail(BBH_ERR_CAPACITY, "tree deeper than %d levels", MAXD);
+            case STOP_DEPTH: return bb::fail(BBH_ERR_CAPACITY, "tree deeper than %d levels (or corrupt link)", MAXD);
             case STOP_RANGE: return bb::fail(BBH_ERR_INVALID, "n_samples exceeds 2^32-1 (engine limit)");
             default: return bb::fail(BBH_ERR_HIP, "unknown stop reason %d", back.stop_reason);
         }
@@ -1161,19 +1417,18 @@ int build_chain(bbh_tree* t) {
     if (t->chain_valid) return BBH_OK;
     TreeDev& h = t->h;
     const uint32_t nn = h.ctr[C_NODES];
-    std::vector<uint32_t> len(nn), next(nn);
-    BB_HIP(hipMemcpy(len.data(), h.node_len, (size_t)nn * 4, hipMemcpyDeviceToHost));
-    BB_HIP(hipMemcpy(next.data(), h.node_next, (size_t)nn * 4, hipMemcpyDeviceToHost));
+    std::vector<NodeHdr> hdr(nn);
+    BB_HIP(hipMemcpy(hdr.data(), h.node_hdr, (size_t)nn * sizeof(NodeHdr), hipMemcpyDeviceToHost));
     t->chain_nodes.clear();
     t->chain_rows.clear();
     uint32_t nd = h.ctr[C_FIRST_LEAF];
     size_t guard = 0;
-    while (nd != NONE && guard++ <= nn) {
-        for (uint32_t r = 0; r < len[nd]; ++r) {
+    while (nd != NONE && nd < nn && guard++ <= nn) {
+        for (uint32_t r = 0; r < hdr[nd].len; ++r) {
             t->chain_nodes.push_back(nd);
             t->chain_rows.push_back(r);
         }
-        nd = next[nd];
+        nd = hdr[nd].next;
     }
     const size_t k = t->chain_nodes.size();
     if (k > t->d_chain_cap) {
@@ -1191,6 +1446,8 @@ int build_chain(bbh_tree* t) {
     t->chain_valid = true;
     return BBH_OK;
 }
+
+uint32_t clamp30(uint64_t v) { return (uint32_t)std::min<uint64_t>(0x3FFFFFFFull, v); }
 
 }  // namespace
 
@@ -1247,7 +1504,7 @@ extern "C" int bbh_tree_set_merge(bbh_tree* t, int32_t criterion, double toleran
     t->h.thr = threshold;
     BB_TRY(set_tol(t, tol_table, tol_len));
     if (branching_factor != t->h.bf) {
-        const bool empty = t->h.ctr[C_NODES] == 1 && t->h.ctr[C_SUBS] == 0;
+        const bool empty = t->h.ctr[C_NODES] == 1 && t->h.ctr[C_IDS] == 0;
         if (!empty)
             return bb::fail(BBH_ERR_STATE, "branching_factor can only change on an empty tree: call reset() first");
         if (branching_factor < 2 || branching_factor > MAX_BF)
@@ -1272,9 +1529,9 @@ extern "C" int bbh_tree_fit_packed(bbh_tree* t, const uint8_t* rows, int64_t n, 
     BB_HIP(hipSetDevice(t->device));
     hipStream_t s = (hipStream_t)stream;
     // every fingerprint can become a new leaf BitFeature at tier 0
-    BB_TRY(grow_subs(t, (uint32_t)std::min<uint64_t>(0x3FFFFFFFull, (uint64_t)t->h.ctr[C_SUBS] + (uint64_t)n + (uint64_t)n / 8 + 1024)));
-    BB_TRY(grow_cf(t, 0, (uint32_t)std::min<uint64_t>(0x3FFFFFFFull, (uint64_t)t->h.ctr[C_N8] + (uint64_t)n + 64)));
-    BB_TRY(grow_nodes(t, (uint32_t)std::min<uint64_t>(0x3FFFFFFFull, (uint64_t)t->h.ctr[C_NODES] + (uint64_t)n / std::max(1, t->h.bf / 3) + 64)));
+    BB_TRY(grow_cf(t, 0, clamp30((uint64_t)t->h.ctr[C_N8] + (uint64_t)n + 64)));
+    BB_TRY(grow_nodes(t, clamp30((uint64_t)t->h.ctr[C_NODES] + (uint64_t)n / std::max(1, t->h.bf / 3) + 64)));
+    BB_TRY(grow_cf(t, 2, clamp30((uint64_t)t->h.ctr[C_N32] + (uint64_t)n / std::max(1, t->h.bf / 6) + 256)));
     bb::DevOut o;
     BB_TRY(o.init(out_leaf, (size_t)n * 4));
     if (bb::is_device_ptr(rows)) {
@@ -1308,10 +1565,10 @@ extern "C" int bbh_tree_fit_buffers(bbh_tree* t, const void* bufs, int32_t width
     if (k == 0) return BBH_OK;
     BB_HIP(hipSetDevice(t->device));
     hipStream_t s = (hipStream_t)stream;
-    BB_TRY(grow_subs(t, (uint32_t)std::min<uint64_t>(0x3FFFFFFFull, (uint64_t)t->h.ctr[C_SUBS] + (uint64_t)k + (uint64_t)k / 8 + 1024)));
-    if (width == 1) BB_TRY(grow_cf(t, 0, (uint32_t)std::min<uint64_t>(0x3FFFFFFFull, (uint64_t)t->h.ctr[C_N8] + (uint64_t)k + 64)));
-    if (width == 2) BB_TRY(grow_cf(t, 1, (uint32_t)std::min<uint64_t>(0x3FFFFFFFull, (uint64_t)t->h.ctr[C_N16] + (uint64_t)k + 64)));
-    BB_TRY(grow_nodes(t, (uint32_t)std::min<uint64_t>(0x3FFFFFFFull, (uint64_t)t->h.ctr[C_NODES] + (uint64_t)k / std::max(1, t->h.bf / 3) + 64)));
+    if (width == 1) BB_TRY(grow_cf(t, 0, clamp30((uint64_t)t->h.ctr[C_N8] + (uint64_t)k + 64)));
+    if (width == 2) BB_TRY(grow_cf(t, 1, clamp30((uint64_t)t->h.ctr[C_N16] + (uint64_t)k + 64)));
+    BB_TRY(grow_nodes(t, clamp30((uint64_t)t->h.ctr[C_NODES] + (uint64_t)k / std::max(1, t->h.bf / 3) + 64)));
+    BB_TRY(grow_cf(t, 2, clamp30((uint64_t)t->h.ctr[C_N32] + (uint64_t)k / std::max(1, t->h.bf / 6) + 256)));
     const size_t row_bytes = ((size_t)t->h.F + 1) * width;
     bb::DevOut o;
     BB_TRY(o.init(out_leaf, (size_t)k * 4));
@@ -1412,6 +1669,12 @@ extern "C" int bbh_tree_gather_buffers(bbh_tree* t, const int64_t* positions, in
 extern "C" int bbh_tree_stats(bbh_tree* t, uint64_t* out8) {
     if (!t || !out8) return bb::fail(BBH_ERR_INVALID, "null argument");
     for (int i = 0; i < 7; ++i) out8[i] = t->h.stats[i];
-    out8[7] = t->h.ctr[C_SUBS];
+    out8[7] = t->h.ctr[C_IDS];
+    if (getenv("BBHIP_PHASES")) {
+        fprintf(stderr, "[bbhip phases, cycles/insert]");
+        const double n = (double)(t->h.stats[2] + t->h.stats[3]);
+        for (int i = 0; i < 8; ++i) fprintf(stderr, " p%d=%.0f", i, n > 0 ? (double)t->h.phase[i] / n : 0.0);
+        fprintf(stderr, "\n");
+    }
     return BBH_OK;
 }
