@@ -1,0 +1,380 @@
+r"""Multi-round BitBIRCH (reference: bblean/multiround.py) on the MI355X engine.
+
+Two front ends over the same round logic:
+
+* `run_multiround_bitbirch` - same signature, file names and file formats as the reference
+  (`multiround.py:333-484`): shard s = input file s, round 1 fits every shard (+ optional
+  refinement), later rounds re-insert the leaf BitFeature tables batch by batch, exchanging
+  `round-{r}-bufs.label-{L}-uint{08,16,..}.npy` / `round-{r}-idxs....pkl` files
+  (`multiround.py:132-143`).  One process, one GPU: the shards run back to back on the device.
+
+* `run_multiround_distributed` - one process per GPU (`torch.distributed`, backend "nccl" =
+  RCCL over xGMI; "gloo" in the CPU tests).  Round 1 is embarrassingly parallel (rank r owns
+  shards r, r+W, ...).  Between rounds the leaf BitFeature tables are exchanged with a
+  variable-size all-gather instead of files; the merge rounds keep the reference's batch
+  composition and order (name-sorted pairs chunked by `bin_size`, uint16 tables before uint8
+  inside a mid-round batch, plain name order in the final round), so the result is identical
+  to the file-based run and to the reference for any number of ranks.
+"""
+from __future__ import annotations
+
+import math
+import pickle
+import time
+import typing as tp
+from pathlib import Path
+
+import numpy as np
+from numpy.typing import NDArray
+
+from bblean_amd.bitbirch import BitBirch, _IndexLists
+from bblean_amd.utils import batched
+
+__all__ = ["run_multiround_bitbirch", "run_multiround_distributed"]
+
+# reference defaults (bblean/_config.py:23-33)
+_DEF = dict(threshold=0.30, branching_factor=254, merge_criterion="diameter",
+            refine_merge_criterion="tolerance-diameter", refine_threshold_change=0.0, tolerance=0.05)
+
+
+class _Timer:
+    def __init__(self) -> None:
+        self.timings: dict[str, float] = {}
+        self._t0: dict[str, float] = {}
+
+    def init_timing(self, label: str) -> None:
+        self._t0[label] = time.perf_counter()
+
+    def end_timing(self, label: str) -> None:
+        self.timings[label] = time.perf_counter() - self._t0.pop(label)
+
+
+def _suffix(label: str, dtype_name: str) -> str:
+    return f".label-{label}-{dtype_name.replace('8', '08')}"  # multiround.py:139
+
+
+def _bits_of(name: str) -> int:
+    return int(name.split("uint")[-1].split(".")[0])  # multiround.py:108
+
+
+def _file_rows(path: Path) -> int:
+    with open(path, "rb") as f:
+        major, minor = np.lib.format.read_magic(f)
+        shape, _, _ = getattr(np.lib.format, f"read_array_header_{major}_{minor}")(f)
+    return shape[0]
+
+
+def _files_range_tuples(files: tp.Sequence[Path]) -> list[tuple[str, Path, int, int]]:
+    r"""(label, file, first global index, end) per shard (multiround.py:316-327)."""
+    out, run = [], 0
+    z = len(str(len(files)))
+    for i, f in enumerate(files):
+        n = _file_rows(f)
+        out.append((str(i).zfill(z), Path(f), run, run + n))
+        run += n
+    return out
+
+
+Tables = tuple[dict[str, NDArray[np.integer]], dict[str, _IndexLists]]
+
+
+def _initial_round(
+    info: tuple[str, Path, int, int], *, branching_factor: int, threshold: float, tolerance: float,
+    merge_criterion: str, refinement: str, refine_merge_criterion: str, refine_threshold_change: float,
+    n_features: int | None, input_is_packed: bool, max_fps: int | None, engine_factory: tp.Any, device: int,
+) -> Tables:
+    r"""`_InitialRound.__call__` (multiround.py:175-216) returning tables instead of files."""
+    _, fp_file, start, end = info
+    tree = BitBirch(branching_factor=branching_factor, threshold=threshold, merge_criterion=merge_criterion,
+                    device=device, _engine_factory=engine_factory)
+    tree.fit(fp_file, reinsert_indices=range(start, end), n_features=n_features,
+             input_is_packed=input_is_packed, max_fps=max_fps)
+    tree.delete_internal_nodes()
+    if refinement == "none":
+        bufs, mols = tree._bf_tables(tree._leaf_order(True))
+    else:
+        bufs, mols = tree._refine_tables(fp_file, initial_mol=start, input_is_packed=input_is_packed)
+        if refinement == "full":
+            tree.reset()
+            tree.set_merge(refine_merge_criterion, tolerance=tolerance,
+                           threshold=threshold + refine_threshold_change)
+            for name in bufs:
+                tree._fit_buffers(bufs[name], reinsert_index_seqs=mols[name])
+            tree.delete_internal_nodes()
+            bufs, mols = tree._bf_tables(tree._leaf_order(True))
+    return bufs, mols
+
+
+def _merge_round(
+    pairs: tp.Sequence[tuple[NDArray[np.integer], _IndexLists]], *, branching_factor: int, threshold: float,
+    tolerance: float, criterion: str, engine_factory: tp.Any, device: int,
+    split_largest: bool = False, all_fp_paths: tp.Sequence[Path] = (),
+) -> BitBirch:
+    r"""`_TreeMergingRound.__call__` (multiround.py:240-264): rebuild one tree from the
+    BitFeature tables of a batch, in the given order."""
+    tree = BitBirch(branching_factor=branching_factor, threshold=threshold, merge_criterion=criterion,
+                    tolerance=tolerance, device=device, _engine_factory=engine_factory)
+    for bufs, idx in pairs:
+        tree._fit_buffers(bufs, reinsert_index_seqs=idx)
+    tree.delete_internal_nodes()
+    return tree
+
+
+def _save_tables(out_dir: Path, bufs: dict, mols: dict, label: str, round_idx: int) -> None:
+    r"""`_save_bufs_and_mol_idxs` (multiround.py:132-143): same names, same bytes."""
+    for name, table in bufs.items():
+        suf = _suffix(label, name)
+        np.save(out_dir / f"round-{round_idx}-bufs{suf}.npy", np.ascontiguousarray(table))
+        with open(out_dir / f"round-{round_idx}-idxs{suf}.pkl", "wb") as f:
+            pickle.dump(mols[name].to_lists(), f)
+
+
+def _load_pair(buf_path: Path, idx_path: Path) -> tuple[NDArray[np.integer], _IndexLists]:
+    with open(idx_path, "rb") as f:
+        lists = pickle.load(f)
+    bufs = np.load(buf_path, mmap_mode="r")
+    return bufs, _IndexLists.from_sequences(lists, len(lists))
+
+
+def run_multiround_bitbirch(
+    input_files: tp.Sequence[Path],
+    out_dir: Path,
+    n_features: int | None = None,
+    input_is_packed: bool = True,
+    num_initial_processes: int = 10,
+    num_midsection_processes: int | None = None,
+    initial_merge_criterion: str = _DEF["merge_criterion"],
+    branching_factor: int = _DEF["branching_factor"],
+    threshold: float = _DEF["threshold"],
+    midsection_threshold_change: float = _DEF["refine_threshold_change"],
+    tolerance: float = _DEF["tolerance"],
+    num_midsection_rounds: int = 1,
+    bin_size: int = 10,
+    max_tasks_per_process: int = 1,
+    refinement_before_midsection: str = "full",
+    split_largest_after_each_midsection_round: bool = False,
+    midsection_merge_criterion: str = _DEF["refine_merge_criterion"],
+    final_merge_criterion: str | None = None,
+    mp_context: tp.Any = None,
+    save_tree: bool = False,
+    save_centroids: bool = True,
+    max_fps: int | None = None,
+    verbose: bool = False,
+    cleanup: bool = True,
+    device: int = 0,
+    _engine_factory: tp.Any = None,
+) -> _Timer:
+    r"""File-compatible multiround on one GPU.  The process-count arguments are accepted for
+    signature compatibility; the result never depended on them (tests/test_multiround.py of the
+    reference asserts that) and the shards simply run back to back on the device."""
+    if refinement_before_midsection not in ("full", "split", "none"):
+        raise ValueError(f"Unknown refinement kind {refinement_before_midsection}")
+    if num_midsection_processes is not None and num_midsection_processes > num_initial_processes:
+        raise ValueError("Num. midsection procs. must be <= num. initial processes")
+    if final_merge_criterion is None:
+        final_merge_criterion = midsection_merge_criterion
+    out_dir = Path(out_dir)
+    input_files = [Path(f) for f in input_files]
+    common = dict(branching_factor=branching_factor, tolerance=tolerance, engine_factory=_engine_factory, device=device)
+    timer = _Timer()
+    timer.init_timing("total")
+
+    round_idx = 1
+    timer.init_timing(f"round-{round_idx}")
+    for info in _files_range_tuples(input_files):
+        bufs, mols = _initial_round(
+            info, threshold=threshold, merge_criterion=initial_merge_criterion,
+            refinement=refinement_before_midsection, refine_merge_criterion=midsection_merge_criterion,
+            refine_threshold_change=midsection_threshold_change, n_features=n_features,
+            input_is_packed=input_is_packed, max_fps=max_fps, **common)
+        _save_tables(out_dir, bufs, mols, info[0], 1)
+    timer.end_timing(f"round-{round_idx}")
+
+    def prev_pairs(r: int) -> list[tuple[Path, Path]]:
+        return list(zip(sorted(out_dir.glob(f"round-{r - 1}-bufs*.npy")),
+                        sorted(out_dir.glob(f"round-{r - 1}-idxs*.pkl"))))
+
+    for _ in range(num_midsection_rounds):
+        round_idx += 1
+        timer.init_timing(f"round-{round_idx}")
+        pairs = prev_pairs(round_idx)
+        z = len(str(math.ceil(len(pairs) / bin_size)))
+        for i, batch in enumerate(batched(pairs, bin_size)):
+            batch = sorted(batch, key=lambda p: _bits_of(p[0].name), reverse=True)  # multiround.py:104-111
+            tree = _merge_round([_load_pair(*p) for p in batch], threshold=threshold + midsection_threshold_change,
+                                criterion=midsection_merge_criterion, **common)
+            if split_largest_after_each_midsection_round:
+                bufs, mols = tree._refine_tables(input_files)
+            else:
+                bufs, mols = tree._bf_tables(tree._leaf_order(True))
+            _save_tables(out_dir, bufs, mols, str(i).zfill(z), round_idx)
+        timer.end_timing(f"round-{round_idx}")
+
+    round_idx += 1
+    timer.init_timing(f"round-{round_idx}")
+    tree = _merge_round([_load_pair(*p) for p in prev_pairs(round_idx)],
+                        threshold=threshold + midsection_threshold_change, criterion=final_merge_criterion, **common)
+    if save_tree:
+        raise NotImplementedError("whole-tree pickling is not provided (the reference's --save-tree is broken too)")
+    _write_outputs(out_dir, tree, save_centroids)
+    timer.end_timing(f"round-{round_idx}")
+    if cleanup:
+        for f in list(out_dir.glob("round-*.npy")) + list(out_dir.glob("round-*.pkl")):
+            f.unlink()
+    timer.end_timing("total")
+    return timer
+
+
+def _write_outputs(out_dir: Path, tree: BitBirch, save_centroids: bool) -> None:
+    r"""clusters.pkl / cluster-centroids-packed.pkl (multiround.py:303-312)."""
+    if save_centroids:
+        out = tree.get_centroids_mol_ids()
+        with open(out_dir / "clusters.pkl", "wb") as f:
+            pickle.dump(out["mol_ids"], f)
+        with open(out_dir / "cluster-centroids-packed.pkl", "wb") as f:
+            pickle.dump(out["centroids"], f)
+    else:
+        with open(out_dir / "clusters.pkl", "wb") as f:
+            pickle.dump(tree.get_cluster_mol_ids(), f)
+
+
+# ------------------------------------------------------------------------------------------
+# one process per GPU
+# ------------------------------------------------------------------------------------------
+_CODE = {"uint8": 8, "uint16": 16, "uint32": 32, "uint64": 64}
+
+
+def _allgather_tables(
+    mine: list[tuple[str, str, NDArray[np.integer], _IndexLists]], dist: tp.Any, device: tp.Any
+) -> list[tuple[str, str, NDArray[np.integer], _IndexLists]]:
+    r"""Variable-size all-gather of (label, dtype, table, member lists) entries: one
+    all-gather of the per-rank descriptors, then one padded all-gather per payload kind (table
+    bytes, member counts, member ids).  With backend "nccl" this is RCCL over xGMI."""
+    import torch
+
+    world = dist.get_world_size()
+    desc = [(lab, name, int(t.shape[0]), int(t.shape[1]), int(idx.flat.size)) for lab, name, t, idx in mine]
+    all_desc: list[tp.Any] = [None] * world
+    dist.all_gather_object(all_desc, desc)
+
+    def gather_bytes(chunks: list[NDArray], dtype: tp.Any) -> list[NDArray]:
+        flat = np.concatenate([np.ascontiguousarray(c).view(np.uint8).reshape(-1) for c in chunks]) if chunks \
+            else np.zeros(0, dtype=np.uint8)
+        sizes = [None] * world
+        dist.all_gather_object(sizes, int(flat.size))
+        cap = max(max(sizes), 1)
+        send = torch.zeros(cap, dtype=torch.uint8, device=device)
+        if flat.size:
+            send[: flat.size] = torch.from_numpy(flat).to(device)
+        recv = [torch.empty(cap, dtype=torch.uint8, device=device) for _ in range(world)]
+        dist.all_gather(recv, send)
+        return [r[: sizes[i]].cpu().numpy().view(dtype) for i, r in enumerate(recv)]
+
+    tables_b = gather_bytes([t for _, _, t, _ in mine], np.uint8)
+    counts_b = gather_bytes([idx.counts.astype(np.int64) for *_, idx in mine], np.int64)
+    ids_b = gather_bytes([idx.flat.astype(np.int64) for *_, idx in mine], np.int64)
+    out = []
+    for r in range(world):
+        tb, cb, ib = tables_b[r], counts_b[r], ids_b[r]
+        to, co, io = 0, 0, 0
+        for lab, name, k, cols, nids in all_desc[r]:
+            item = np.dtype(name).itemsize
+            table = tb[to: to + k * cols * item].view(np.dtype(name)).reshape(k, cols)
+            to += k * cols * item
+            cnt = cb[co: co + k]
+            co += k
+            ids = ib[io: io + nids]
+            io += nids
+            out.append((lab, name, table, _IndexLists(cnt.copy(), ids.copy())))
+    return out
+
+
+def run_multiround_distributed(
+    input_files: tp.Sequence[Path],
+    out_dir: Path | None = None,
+    *,
+    n_features: int | None = None,
+    input_is_packed: bool = True,
+    initial_merge_criterion: str = _DEF["merge_criterion"],
+    branching_factor: int = _DEF["branching_factor"],
+    threshold: float = _DEF["threshold"],
+    midsection_threshold_change: float = _DEF["refine_threshold_change"],
+    tolerance: float = _DEF["tolerance"],
+    num_midsection_rounds: int = 1,
+    bin_size: int = 10,
+    refinement_before_midsection: str = "full",
+    midsection_merge_criterion: str = _DEF["refine_merge_criterion"],
+    final_merge_criterion: str | None = None,
+    save_centroids: bool = True,
+    max_fps: int | None = None,
+    device: int | None = None,
+    _engine_factory: tp.Any = None,
+) -> tuple[list[list[int]] | None, _Timer]:
+    r"""Multiround with one rank per GPU (`torch.distributed` must be initialised).  Returns
+    (clusters on rank 0 / None elsewhere, timings); also writes clusters.pkl on rank 0 when
+    `out_dir` is given."""
+    import torch
+    import torch.distributed as dist
+
+    if final_merge_criterion is None:
+        final_merge_criterion = midsection_merge_criterion
+    rank, world = dist.get_rank(), dist.get_world_size()
+    on_gpu = dist.get_backend() == "nccl"
+    dev_index = (torch.cuda.current_device() if device is None else device) if on_gpu else 0
+    tdev = torch.device("cuda", dev_index) if on_gpu else torch.device("cpu")
+    common = dict(branching_factor=branching_factor, tolerance=tolerance, engine_factory=_engine_factory, device=dev_index)
+    timer = _Timer()
+    timer.init_timing("total")
+
+    # round 1: rank r owns shards r, r+W, ...  (no collective)
+    timer.init_timing("round-1")
+    infos = _files_range_tuples([Path(f) for f in input_files])
+    mine = []
+    for i, info in enumerate(infos):
+        if i % world != rank:
+            continue
+        bufs, mols = _initial_round(
+            info, threshold=threshold, merge_criterion=initial_merge_criterion,
+            refinement=refinement_before_midsection, refine_merge_criterion=midsection_merge_criterion,
+            refine_threshold_change=midsection_threshold_change, n_features=n_features,
+            input_is_packed=input_is_packed, max_fps=max_fps, **common)
+        for name in bufs:
+            mine.append((info[0], name, bufs[name], mols[name]))
+    timer.end_timing("round-1")
+
+    def ordered(entries: list) -> list:
+        # the order sorted(glob("round-*-bufs*.npy")) gives: by file name = (label, uintNN)
+        return sorted(entries, key=lambda e: f"label-{e[0]}-{e[1].replace('8', '08')}")
+
+    round_idx = 1
+    for _ in range(num_midsection_rounds):
+        round_idx += 1
+        timer.init_timing(f"round-{round_idx}")
+        everything = ordered(_allgather_tables(mine, dist, tdev))
+        z = len(str(math.ceil(len(everything) / bin_size)))
+        mine = []
+        for b, batch in enumerate(batched(everything, bin_size)):
+            if b % world != rank:
+                continue
+            batch = sorted(batch, key=lambda e: _CODE[e[1]], reverse=True)  # uint16 tables first
+            tree = _merge_round([(t, idx) for _, _, t, idx in batch], threshold=threshold + midsection_threshold_change,
+                                criterion=midsection_merge_criterion, **common)
+            bufs, mols = tree._bf_tables(tree._leaf_order(True))
+            for name in bufs:
+                mine.append((str(b).zfill(z), name, bufs[name], mols[name]))
+        timer.end_timing(f"round-{round_idx}")
+
+    round_idx += 1
+    timer.init_timing(f"round-{round_idx}")
+    everything = ordered(_allgather_tables(mine, dist, tdev))
+    clusters = None
+    if rank == 0:
+        tree = _merge_round([(t, idx) for _, _, t, idx in everything], threshold=threshold + midsection_threshold_change,
+                            criterion=final_merge_criterion, **common)
+        clusters = tree.get_cluster_mol_ids()
+        if out_dir is not None:
+            _write_outputs(Path(out_dir), tree, save_centroids)
+    dist.barrier()
+    timer.end_timing(f"round-{round_idx}")
+    timer.end_timing("total")
+    return clusters, timer

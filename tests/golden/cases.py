@@ -84,3 +84,19 @@ TREE_CASES = [
     _c("splitfit_2500", 2500, 50, 0.3, "diameter", seed=41, fit_splits=[700, 1900]),
     _c("reinsert_1000", 1000, 50, 0.3, "diameter", seed=42, reinsert_offset=5000),
 ]
+
+
+# multiround fixtures: files of make_fake_fingerprints(n_per_file, seed=s) for s in seeds
+MULTIROUND_CASES = [
+    # the reference's own test (tests/test_multiround.py:9-48)
+    dict(name="mr_ref_test", seeds=list(range(1, 21, 2)), n_per_file=100,
+         kwargs=dict(bin_size=2, threshold=0.65, midsection_merge_criterion="tolerance-legacy")),
+    # CLI defaults at test scale (tolerance-diameter merge rounds, full refinement)
+    dict(name="mr_defaults", seeds=[101, 102, 103, 104, 105, 106], n_per_file=400,
+         kwargs=dict(bin_size=4, threshold=0.3, branching_factor=50)),
+    dict(name="mr_split_2mid", seeds=[201, 202, 203, 204, 205], n_per_file=300,
+         kwargs=dict(bin_size=2, threshold=0.3, branching_factor=30, num_midsection_rounds=2,
+                     refinement_before_midsection="split")),
+    dict(name="mr_none_big", seeds=[301, 302, 303], n_per_file=1500,
+         kwargs=dict(bin_size=10, threshold=0.2, branching_factor=50, refinement_before_midsection="none")),
+]

@@ -1,0 +1,113 @@
+r"""Multiround host logic (bblean_amd/multiround.py) against outputs of the reference's
+run_multiround_bitbirch (tests/golden/multiround.npz).  CPU tests inject the oracle engine;
+the distributed path runs as 2 gloo ranks; the gpu-marked test runs the same on the HIP engine."""
+from __future__ import annotations
+
+import os
+import pickle
+import socket
+import subprocess
+import sys
+import tempfile
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from cases import MULTIROUND_CASES
+from oracle_engine import OracleEngine
+
+from bblean_amd import make_fake_fingerprints
+from bblean_amd.multiround import run_multiround_bitbirch
+
+GOLD = dict(np.load(Path(__file__).resolve().parent / "golden" / "multiround.npz"))
+REPO = Path(__file__).resolve().parents[1]
+
+
+def _write_files(d: Path, case: dict) -> list[Path]:
+    for s in case["seeds"]:
+        np.save(d / f"fps.{str(s).zfill(4)}.npy", make_fake_fingerprints(case["n_per_file"], seed=s))
+    return sorted(d.glob("*.npy"))
+
+
+def _check(case: dict, clusters, cents=None) -> None:
+    name = case["name"]
+    assert [len(c) for c in clusters] == GOLD[name + "_sizes"].tolist()
+    assert [i for c in clusters for i in c] == GOLD[name + "_members"].tolist()
+    if cents is not None:
+        assert (np.array(cents, dtype=np.uint8) == GOLD[name + "_cents"]).all()
+
+
+def _run_files(case: dict, engine_factory) -> None:
+    with tempfile.TemporaryDirectory() as d:
+        d = Path(d)
+        files = _write_files(d, case)
+        (d / "out").mkdir()
+        run_multiround_bitbirch(files, d / "out", num_initial_processes=1, _engine_factory=engine_factory, **case["kwargs"])
+        clusters = pickle.load(open(d / "out" / "clusters.pkl", "rb"))
+        cents = pickle.load(open(d / "out" / "cluster-centroids-packed.pkl", "rb"))
+        assert not list((d / "out").glob("round-*"))  # cleanup like the reference
+    _check(case, clusters, cents)
+
+
+@pytest.mark.parametrize("case", MULTIROUND_CASES, ids=[c["name"] for c in MULTIROUND_CASES])
+def test_multiround_files_oracle(case):
+    _run_files(case, OracleEngine)
+
+
+def test_reference_known_clusters():
+    r"""First clusters asserted by the reference's tests/test_multiround.py:51-80."""
+    sizes, mem = GOLD["mr_ref_test_sizes"], GOLD["mr_ref_test_members"]
+    assert mem[: sizes[0]].tolist() == [368, 414, 422, 423, 520, 549, 581, 609, 625, 683, 622, 709, 761, 770,
+                                        789, 813, 831, 989]
+    assert mem[sizes[0]: sizes[0] + sizes[1]].tolist() == [23, 285, 209, 213, 276, 294, 316, 319, 358]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", MULTIROUND_CASES, ids=[c["name"] for c in MULTIROUND_CASES])
+def test_multiround_files_hip(case):
+    _run_files(case, None)
+
+
+_WORKER = r"""
+import os, sys, pickle
+from pathlib import Path
+sys.path.insert(0, {repo!r}); sys.path.insert(0, {repo!r} + "/tests"); sys.path.insert(0, {repo!r} + "/tests/golden")
+import torch.distributed as dist
+from bblean_amd.multiround import run_multiround_distributed
+engine = None
+if {use_oracle}:
+    from oracle_engine import OracleEngine as engine
+dist.init_process_group({backend!r}, init_method="tcp://127.0.0.1:{port}", rank=int(sys.argv[1]), world_size={world})
+files = sorted(Path({d!r}).glob("fps.*.npy"))
+clusters, timer = run_multiround_distributed(files, Path({d!r}) / "out", _engine_factory=engine, **{kwargs!r})
+if dist.get_rank() == 0:
+    pickle.dump(clusters, open(Path({d!r}) / "clusters_rank0.pkl", "wb"))
+dist.destroy_process_group()
+"""
+
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("case", MULTIROUND_CASES[:3], ids=[c["name"] for c in MULTIROUND_CASES[:3]])
+def test_multiround_distributed_gloo_world2(case):
+    r"""Two ranks, gloo, oracle engine: the all-gather exchange must give the reference's result."""
+    kwargs = {k: v for k, v in case["kwargs"].items()}
+    with tempfile.TemporaryDirectory() as d:
+        d = Path(d)
+        _write_files(d, case)
+        (d / "out").mkdir()
+        src = _WORKER.format(repo=str(REPO), use_oracle=True, backend="gloo", port=_free_port(), world=2, d=str(d), kwargs=kwargs)
+        (d / "worker.py").write_text(src)
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+        procs = [subprocess.Popen([sys.executable, str(d / "worker.py"), str(r)], env=env) for r in range(2)]
+        for p in procs:
+            assert p.wait(timeout=600) == 0
+        clusters = pickle.load(open(d / "clusters_rank0.pkl", "rb"))
+        on_disk = pickle.load(open(d / "out" / "clusters.pkl", "rb"))
+    assert clusters == on_disk
+    _check(case, clusters)
