@@ -102,6 +102,34 @@ class HipEngine:
         )
         return out
 
+    @staticmethod
+    def fit_packed_many(engines: "list[HipEngine]", rows_list: list) -> list[NDArray[np.uint32]]:
+        r"""Insert into several trees with ONE kernel launch (one workgroup per tree)."""
+        lib = _lib.load()
+        k = len(engines)
+        keep, ns, strides, outs = [], [], [], []
+        for eng, rows in zip(engines, rows_list):
+            if _is_device_tensor(rows):
+                n, nb, st = int(rows.shape[0]), int(rows.shape[1]), int(rows.stride(0))
+                keep.append(rows)
+            else:
+                arr = np.ascontiguousarray(rows, dtype=np.uint8)
+                n, nb = arr.shape
+                st = nb
+                keep.append(arr)
+            if nb != eng.nbytes:
+                raise RuntimeError(f"rows have {nb} bytes, tree expects {eng.nbytes}")
+            ns.append(n)
+            strides.append(st)
+            outs.append(np.empty(n, dtype=np.uint32))
+        handles = (C.c_void_p * k)(*[e._h for e in engines])
+        rows_p = (C.c_void_p * k)(*[_lib.ptr(r) if len(r) else None for r in keep])
+        n_p = (C.c_int64 * k)(*ns)
+        s_p = (C.c_int64 * k)(*strides)
+        out_p = (C.c_void_p * k)(*[o.ctypes.data if o.size else None for o in outs])
+        _lib.check(lib.bbh_trees_fit_packed(handles, k, rows_p, n_p, s_p, out_p, None))
+        return outs
+
     def fit_buffers(self, bufs: NDArray[np.integer], stream: int | None = None) -> NDArray[np.uint32]:
         r"""Insert BitFeature buffers, shape (k, n_features + 1), unsigned dtype."""
         bufs = np.ascontiguousarray(bufs)

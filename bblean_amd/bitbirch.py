@@ -30,7 +30,7 @@ from bblean_amd._merges import BUILTIN_MERGES, MergeCriterion, get_merge_accept_
 from bblean_amd.fingerprints import pack_fingerprints, unpack_fingerprints
 from bblean_amd.utils import min_safe_uint
 
-__all__ = ["BitBirch", "set_merge"]
+__all__ = ["BitBirch", "set_merge", "fit_concurrently"]
 
 _Input = tp.Union[NDArray[np.integer], list]
 
@@ -312,6 +312,14 @@ class BitBirch:
         ``X``: packed/unpacked array, list of rows, ``.npy`` path, or a device-resident
         ``torch.uint8`` tensor of packed rows (used in place, no PCIe copy).
         """
+        rows, ids = self._prepare_fit(X, reinsert_indices, input_is_packed, n_features, max_fps)
+        if len(ids):
+            self._commit_fit(self._engine.fit_packed(rows), ids)
+        return self
+
+    def _prepare_fit(self, X, reinsert_indices, input_is_packed, n_features, max_fps):  # type: ignore[no-untyped-def]
+        r"""Everything `fit` does before the hot loop: load / validate / pack the input, create the
+        engine, resolve the molecule indices.  Returns (packed rows, indices)."""
         is_dev = hasattr(X, "data_ptr") and getattr(X, "is_cuda", False)
         if isinstance(X, (Path, str)):
             X = np.load(Path(X), mmap_mode="r")
@@ -357,14 +365,14 @@ class BitBirch:
             rows = rows[:n_rows]
         ids = ids[:n_rows]
         self._is_init = True
-        if n_rows:
-            leaf = self._engine.fit_packed(rows)
-            self._log_leaf.append(leaf)
-            self._log_counts.append(None)
-            self._log_ids.append(ids)
-            self._num_fitted_fps += n_rows
-            self._cache.clear()
-        return self
+        return rows, ids
+
+    def _commit_fit(self, leaf: NDArray[np.uint32], ids: NDArray[np.int64]) -> None:
+        self._log_leaf.append(leaf)
+        self._log_counts.append(None)
+        self._log_ids.append(ids)
+        self._num_fitted_fps += int(ids.size)
+        self._cache.clear()
 
     def fit_reinsert(self, X, reinsert_indices, input_is_packed=True, n_features=None, max_fps=None):  # type: ignore[no-untyped-def]
         r""":meta private: (reference bitbirch.py:868-878)"""
@@ -827,6 +835,35 @@ class BitBirch:
         if self.tolerance is not None:
             parts.append(f"tolerance={self.tolerance}")
         return f"{self.__class__.__name__}({', '.join(parts)})"
+
+
+def fit_concurrently(
+    trees: tp.Sequence[BitBirch],
+    inputs: tp.Sequence[tp.Any],
+    reinsert_indices: tp.Sequence[tp.Iterable[int] | None] | None = None,
+    input_is_packed: bool = True,
+    n_features: int | None = None,
+    max_fps: int | None = None,
+) -> None:
+    r"""`tree.fit(X)` for several independent trees at once - the shards of multiround's first
+    round (reference multiround.py:401-422 runs them in a process pool).  On the HIP engine all
+    trees insert in ONE kernel launch, one workgroup per tree, concurrently on different compute
+    units; results are identical to calling `fit` on each tree in turn."""
+    if len(trees) != len(inputs):
+        raise ValueError("need one input per tree")
+    prepared = []
+    for i, (t, X) in enumerate(zip(trees, inputs)):
+        ri = None if reinsert_indices is None else reinsert_indices[i]
+        prepared.append(t._prepare_fit(X, ri, input_is_packed, n_features, max_fps))
+    engines = [t._engine for t in trees]
+    many = getattr(type(engines[0]), "fit_packed_many", None) if engines else None
+    if many is not None and all(type(e) is type(engines[0]) for e in engines):
+        leaves = many(engines, [rows for rows, _ in prepared])
+    else:
+        leaves = [e.fit_packed(rows) for e, (rows, _) in zip(engines, prepared)]
+    for t, leaf, (_, ids) in zip(trees, leaves, prepared):
+        if len(ids):
+            t._commit_fit(leaf, ids)
 
 
 def _rows_from_file_seq(files: tp.Sequence[Path], idxs: NDArray[np.int64]) -> NDArray[np.uint8]:

@@ -1361,55 +1361,102 @@ int configure(bbh_tree* t, int32_t bf, int32_t n_features) {
     return BBH_OK;
 }
 
-// run the insertion kernel over n elements, growing pools whenever it stops for capacity
-int run_insert(bbh_tree* t, const uint8_t* rows_dev, int64_t row_stride, const uint8_t* bufs_dev, int width, int64_t n,
-               uint32_t* out_leaf_dev, hipStream_t s) {
-    TreeDev& h = t->h;
-    t->chain_valid = false;
-    int64_t done = 0;
-    int stalls = 0;
-    while (done < n) {
-        h.rows = rows_dev ? rows_dev + done * row_stride : nullptr;
-        h.row_stride = row_stride;
-        h.bufs = bufs_dev ? bufs_dev + (size_t)done * ((size_t)h.F + 1) * width : nullptr;
-        h.width = width;
-        h.n_elems = n - done;
-        h.out_leaf = out_leaf_dev ? out_leaf_dev + done : nullptr;
-        BB_HIP(hipMemcpyAsync(t->d, &h, sizeof(TreeDev), hipMemcpyHostToDevice, s));
+// One insertion job: a tree and the elements to insert into it.
+struct Job {
+    bbh_tree* t;
+    const uint8_t* rows;  // device
+    int64_t row_stride;
+    const uint8_t* bufs;  // device
+    int width;
+    int64_t n;
+    uint32_t* out;  // device or null
+    int64_t done;
+    int stalls;
+};
+
+// Run the insertion kernel over all jobs, ONE WORKGROUP PER TREE in a single launch (independent
+// trees - multiround shards - run concurrently on different CUs), relaunching the unfinished
+// ones after growing whatever pool made them stop.
+int run_insert_multi(std::vector<Job>& jobs, hipStream_t s) {
+    if (jobs.empty()) return BBH_OK;
+    TreeDev* darr = nullptr;
+    const bool single = jobs.size() == 1;
+    if (!single) BB_HIP(hipMalloc(&darr, jobs.size() * sizeof(TreeDev)));
+    std::vector<TreeDev> harr(jobs.size());
+    std::vector<size_t> active;
+    int rc = BBH_OK;
+    size_t lds = 0;
+    for (auto& j : jobs) {
+        j.t->chain_valid = false;
+        lds = std::max(lds, j.t->lds);
+    }
+    while (rc == BBH_OK) {
+        active.clear();
+        for (size_t i = 0; i < jobs.size(); ++i)
+            if (jobs[i].done < jobs[i].n) active.push_back(i);
+        if (active.empty()) break;
+        for (size_t a = 0; a < active.size(); ++a) {
+            Job& j = jobs[active[a]];
+            TreeDev& h = j.t->h;
+            h.rows = j.rows ? j.rows + j.done * j.row_stride : nullptr;
+            h.row_stride = j.row_stride;
+            h.bufs = j.bufs ? j.bufs + (size_t)j.done * ((size_t)h.F + 1) * j.width : nullptr;
+            h.width = j.width;
+            h.n_elems = j.n - j.done;
+            h.out_leaf = j.out ? j.out + j.done : nullptr;
+            harr[a] = h;
+        }
+        TreeDev* dptr = single ? jobs[0].t->d : darr;
+        hipError_t e = hipMemcpyAsync(dptr, harr.data(), active.size() * sizeof(TreeDev), hipMemcpyHostToDevice, s);
+        if (e != hipSuccess) { rc = bb::fail(BBH_ERR_HIP, "H2D: %s", hipGetErrorString(e)); break; }
         {
             bb::ProfScope ps("tree_insert", s);
-            hipLaunchKernelGGL(k_tree_insert, dim3(1), dim3(TB), t->lds, s, t->d);
-            BB_HIP(hipGetLastError());
+            hipLaunchKernelGGL(k_tree_insert, dim3((unsigned)active.size()), dim3(TB), lds, s, dptr);
+            e = hipGetLastError();
         }
-        TreeDev back;
-        BB_HIP(hipMemcpyAsync(&back, t->d, sizeof(TreeDev), hipMemcpyDeviceToHost, s));
-        BB_HIP(hipStreamSynchronize(s));
-        std::memcpy(h.ctr, back.ctr, sizeof(h.ctr));
-        std::memcpy(h.stats, back.stats, sizeof(h.stats));
-        std::memcpy(h.phase, back.phase, sizeof(h.phase));
-        done += back.processed;
-        stalls = back.processed == 0 ? stalls + 1 : 0;
-        if (stalls > 3) return bb::fail(BBH_ERR_CAPACITY, "tree engine made no progress (stop reason %d)", back.stop_reason);
-        const int64_t left = n - done;
-        auto more = [&](uint32_t used, uint32_t cap, int64_t per_elem_hint) -> uint32_t {
-            uint64_t want = (uint64_t)cap * 2;
-            uint64_t est = (uint64_t)used + (uint64_t)(left * per_elem_hint) / 4 + 4096;
-            if (est > want) want = est;
-            if (want > 0x3FFFFFFFull) want = 0x3FFFFFFFull;
-            return (uint32_t)want;
-        };
-        switch (back.stop_reason) {
-            case STOP_DONE: break;
-            case STOP_NODES: BB_TRY(grow_nodes(t, more(h.ctr[C_NODES], h.cap_nodes, 1))); break;
-            case STOP_CF8: BB_TRY(grow_cf(t, 0, more(h.ctr[C_N8], h.cap8, 4))); break;
-            case STOP_CF16: BB_TRY(grow_cf(t, 1, more(h.ctr[C_N16], h.cap16, 1))); break;
-            case STOP_CF32: BB_TRY(grow_cf(t, 2, more(h.ctr[C_N32], h.cap32, 1))); break;
-            case STOP_DEPTH: return bb::fail(BBH_ERR_CAPACITY, "tree deeper than %d levels (or corrupt link)", MAXD);
-            case STOP_RANGE: return bb::fail(BBH_ERR_INVALID, "n_samples exceeds 2^32-1 (engine limit)");
-            default: return bb::fail(BBH_ERR_HIP, "unknown stop reason %d", back.stop_reason);
+        if (e == hipSuccess) e = hipMemcpyAsync(harr.data(), dptr, active.size() * sizeof(TreeDev), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) { rc = bb::fail(BBH_ERR_HIP, "tree_insert: %s", hipGetErrorString(e)); break; }
+        for (size_t a = 0; a < active.size() && rc == BBH_OK; ++a) {
+            Job& j = jobs[active[a]];
+            bbh_tree* t = j.t;
+            TreeDev& h = t->h;
+            const TreeDev& back = harr[a];
+            std::memcpy(h.ctr, back.ctr, sizeof(h.ctr));
+            std::memcpy(h.stats, back.stats, sizeof(h.stats));
+            std::memcpy(h.phase, back.phase, sizeof(h.phase));
+            j.done += back.processed;
+            j.stalls = back.processed == 0 ? j.stalls + 1 : 0;
+            if (j.stalls > 3) { rc = bb::fail(BBH_ERR_CAPACITY, "tree engine made no progress (stop reason %d)", back.stop_reason); break; }
+            const int64_t left = j.n - j.done;
+            auto more = [&](uint32_t used, uint32_t cap, int64_t per_elem_hint) -> uint32_t {
+                uint64_t want = (uint64_t)cap * 2;
+                uint64_t est = (uint64_t)used + (uint64_t)(left * per_elem_hint) / 4 + 4096;
+                if (est > want) want = est;
+                if (want > 0x3FFFFFFFull) want = 0x3FFFFFFFull;
+                return (uint32_t)want;
+            };
+            switch (back.stop_reason) {
+                case STOP_DONE: break;
+                case STOP_NODES: rc = grow_nodes(t, more(h.ctr[C_NODES], h.cap_nodes, 1)); break;
+                case STOP_CF8: rc = grow_cf(t, 0, more(h.ctr[C_N8], h.cap8, 4)); break;
+                case STOP_CF16: rc = grow_cf(t, 1, more(h.ctr[C_N16], h.cap16, 1)); break;
+                case STOP_CF32: rc = grow_cf(t, 2, more(h.ctr[C_N32], h.cap32, 1)); break;
+                case STOP_DEPTH: rc = bb::fail(BBH_ERR_CAPACITY, "tree deeper than %d levels (or corrupt link)", MAXD); break;
+                case STOP_RANGE: rc = bb::fail(BBH_ERR_INVALID, "n_samples exceeds 2^32-1 (engine limit)"); break;
+                default: rc = bb::fail(BBH_ERR_HIP, "unknown stop reason %d", back.stop_reason); break;
+            }
         }
     }
-    return BBH_OK;
+    if (darr) (void)hipFree(darr);
+    return rc;
+}
+
+int run_insert(bbh_tree* t, const uint8_t* rows_dev, int64_t row_stride, const uint8_t* bufs_dev, int width, int64_t n,
+               uint32_t* out_leaf_dev, hipStream_t s) {
+    std::vector<Job> jobs(1);
+    jobs[0] = Job{t, rows_dev, row_stride, bufs_dev, width, n, out_leaf_dev, 0, 0};
+    return run_insert_multi(jobs, s);
 }
 
 // walk the leaf chain on the host (bitbirch.py:886-893): positions -> (node, row)
@@ -1591,6 +1638,36 @@ extern "C" int bbh_tree_fit_buffers(bbh_tree* t, const void* bufs, int32_t width
         BB_TRY(rc);
     }
     BB_TRY(o.finish(s));
+    BB_HIP(hipStreamSynchronize(s));
+    return BBH_OK;
+}
+
+// Several independent trees (multiround shards) in one launch: one workgroup per tree.
+extern "C" int bbh_trees_fit_packed(bbh_tree** trees, int32_t n_trees, const uint8_t* const* rows, const int64_t* n,
+                                    const int64_t* row_stride, uint32_t* const* out_leaf, void* stream) {
+    if (!trees || n_trees < 0 || !rows || !n || !row_stride) return bb::fail(BBH_ERR_INVALID, "null argument");
+    if (n_trees == 0) return BBH_OK;
+    hipStream_t s = (hipStream_t)stream;
+    std::vector<Job> jobs;
+    std::vector<bb::DevIn> ins((size_t)n_trees);
+    std::vector<bb::DevOut> outs((size_t)n_trees);
+    const int device = trees[0]->device;
+    BB_HIP(hipSetDevice(device));
+    for (int32_t i = 0; i < n_trees; ++i) {
+        bbh_tree* t = trees[i];
+        if (!t || t->device != device) return bb::fail(BBH_ERR_INVALID, "all trees of one call must live on one device");
+        if (n[i] < 0 || row_stride[i] < t->h.nbytes) return bb::fail(BBH_ERR_INVALID, "rows must be (n, n_features/8) uint8");
+        if (n[i] == 0) continue;
+        BB_TRY(grow_cf(t, 0, clamp30((uint64_t)t->h.ctr[C_N8] + (uint64_t)n[i] + 64)));
+        BB_TRY(grow_nodes(t, clamp30((uint64_t)t->h.ctr[C_NODES] + (uint64_t)n[i] / std::max(1, t->h.bf / 3) + 64)));
+        BB_TRY(grow_cf(t, 2, clamp30((uint64_t)t->h.ctr[C_N32] + (uint64_t)n[i] / std::max(1, t->h.bf / 6) + 256)));
+        BB_TRY(ins[(size_t)i].init(rows[i], (size_t)(n[i] * row_stride[i]), s));
+        BB_TRY(outs[(size_t)i].init(out_leaf ? out_leaf[i] : nullptr, (size_t)n[i] * 4));
+        jobs.push_back(Job{t, (const uint8_t*)ins[(size_t)i].dev, row_stride[i], nullptr, 0, n[i],
+                           (uint32_t*)outs[(size_t)i].dev, 0, 0});
+    }
+    BB_TRY(run_insert_multi(jobs, s));
+    for (auto& o : outs) BB_TRY(o.finish(s));
     BB_HIP(hipStreamSynchronize(s));
     return BBH_OK;
 }

@@ -144,6 +144,13 @@ int bbh_tree_reset(bbh_tree* t);
 int bbh_tree_fit_packed(bbh_tree* t, const uint8_t* rows, int64_t n, int64_t row_stride,
                         uint32_t* out_leaf, void* stream);
 
+/* The same for several independent trees (the shards of multiround's first round,
+ * multiround.py:401-422) in ONE kernel launch, one workgroup per tree: the trees insert
+ * concurrently on different compute units.  All trees must live on one device. */
+int bbh_trees_fit_packed(bbh_tree** trees, int32_t n_trees, const uint8_t* const* rows,
+                         const int64_t* n, const int64_t* row_stride, uint32_t* const* out_leaf,
+                         void* stream);
+
 /* BitBirch._fit_buffers hot loop (bitbirch.py:848-866): insert k BitFeature buffers
  * [linear_sum(n_features) | n_samples], elements of `width` bytes (1,2,4,8), row-major
  * with (n_features+1) columns.  Synchronous. */

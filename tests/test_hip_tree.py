@@ -91,3 +91,17 @@ def test_hip_edge_cases():
     t.reset()
     t.fit(make_fake_fingerprints(10, seed=2))
     assert t.num_fitted_fps == 10
+
+
+def test_hip_concurrent_trees_equal_sequential():
+    r"""One launch, one workgroup per tree (multiround round-1 shards) == one tree at a time."""
+    from bblean_amd import fit_concurrently
+
+    shards = [make_fake_fingerprints(3000 + 500 * i, seed=7000 + i) for i in range(9)]
+    together = [BitBirch(branching_factor=50, threshold=0.3) for _ in shards]
+    offs = np.cumsum([0] + [len(s) for s in shards])
+    fit_concurrently(together, shards, reinsert_indices=[range(offs[i], offs[i + 1]) for i in range(len(shards))])
+    for i, s in enumerate(shards):
+        alone = BitBirch(branching_factor=50, threshold=0.3).fit(s, reinsert_indices=range(offs[i], offs[i + 1]))
+        assert together[i].get_cluster_mol_ids() == alone.get_cluster_mol_ids()
+        assert (np.array(together[i].get_centroids()) == np.array(alone.get_centroids())).all()
