@@ -376,24 +376,30 @@ __device__ __forceinline__ Cand node_best(const KC& k, int& cmp_par, uint32_t nd
     uint32_t bi = MINMODE ? 0xFFFFu : 0u, bu = 1u, br = NONE;
     if (k.RBc == 16) {
         const u32x4_t xv = vec[l];
+        const uint32_t last = rows - 1;
         for (uint32_t r0 = 0; r0 < rows; r0 += 64) {
+            // branch-free: row indices are clamped instead of predicated so that all loads of
+            // the pass are issued back to back; out-of-range rows are discarded by `r < len`
             u32x4_t d[4];
             uint32_t cd[4];
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
                 const uint32_t r = r0 + p * 16 + g;
-                d[p] = (u32x4_t)(0);
-                cd[p] = 0;
-                if (r < rows) {
-                    if constexpr (ROOT) {
-                        d[p] = *(LA u32x4_t*)(k.L + k.o.rc_cent + r * k.RBS + l * 16);
-                        if (l == 0) cd[p] = lds<uint32_t>(k.L, k.o.rc_card)[r];
-                    } else {
-                        d[p] = ldg<u32x4_t>(k.cent + (meta + r) * 256 + l * 16);
-                        if (l == 0) {
-                            cd[p] = ldg<uint32_t>(k.card + meta + r);
-                            if (want_link) s_link[r] = ldg<uint32_t>(k.link + meta + r);
-                        }
+                const uint32_t rc = r < last ? r : last;
+                if constexpr (ROOT) {
+                    d[p] = *(LA u32x4_t*)(k.L + k.o.rc_cent + rc * k.RBS + l * 16);
+                    cd[p] = lds<uint32_t>(k.L, k.o.rc_card)[rc];
+                } else {
+                    d[p] = ldg<u32x4_t>(k.cent + (meta + rc) * 256 + l * 16);
+                    cd[p] = ldg<uint32_t>(k.card + meta + rc);
+                }
+            }
+            if constexpr (!ROOT) {
+                if (want_link) {
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) {
+                        const uint32_t r = r0 + p * 16 + g;
+                        if (l == 0 && r < rows) s_link[r] = ldg<uint32_t>(k.link + meta + r);
                     }
                 }
             }
@@ -409,12 +415,15 @@ __device__ __forceinline__ Cand node_best(const KC& k, int& cmp_par, uint32_t nd
             for (int p = 0; p < 4; ++p) {
                 const uint32_t r = r0 + p * 16 + g;
                 // lane 0 of the group carries the row's cardinality in the high half
-                const uint32_t both = row16_sum(popc4v(d[p] & xv) + (cd[p] << 16));
+                const uint32_t both = row16_sum(popc4v(d[p] & xv) + (l == 0 ? cd[p] << 16 : 0u));
                 const uint32_t inter = both & 0xFFFFu;
                 uint32_t un = (both >> 16) + vec_pc - inter;
                 if (want_counts && r < len && l == 0) { s_i[r] = inter; s_u[r] = un; }
                 un = un < 1u ? 1u : un;
-                if (r < len && cand_better<MINMODE>(inter, un, r, bi, bu, br)) { bi = inter; bu = un; br = r; }
+                const bool take = r < len && cand_better<MINMODE>(inter, un, r, bi, bu, br);
+                bi = take ? inter : bi;
+                bu = take ? un : bu;
+                br = take ? r : br;
             }
         }
     } else {
