@@ -105,3 +105,20 @@ def test_hip_concurrent_trees_equal_sequential():
         alone = BitBirch(branching_factor=50, threshold=0.3).fit(s, reinsert_indices=range(offs[i], offs[i + 1]))
         assert together[i].get_cluster_mol_ids() == alone.get_cluster_mol_ids()
         assert (np.array(together[i].get_centroids()) == np.array(alone.get_centroids())).all()
+
+
+def test_hip_tree_full_size_1M_vs_oracle():
+    r"""BASELINE.json configs[1] at full size: 1 M synthetic 2048-bit fingerprints, thr 0.3,
+    bf 50 - cluster ids of the HIP engine must equal the CPU oracle's, element by element."""
+    import torch
+
+    from bench import synth_fake_fps
+
+    fps = synth_fake_fps(1_000_000, seed=1000, device=torch.device("cuda"))
+    hip = BitBirch(branching_factor=50, threshold=0.3, merge_criterion="diameter").fit(fps)
+    ora = BitBirch(branching_factor=50, threshold=0.3, merge_criterion="diameter", _engine_factory=OracleEngine).fit(fps.cpu().numpy())
+    a, b = hip.get_assignments(), ora.get_assignments()
+    assert (a == b).all()
+    assert hip._engine.stats()[:7].tolist() == ora._engine.stats()[:7].tolist()
+    lv_h, lv_o = hip._leaves(), ora._leaves()
+    assert (lv_h["cents"] == lv_o["cents"]).all() and (lv_h["n"] == lv_o["n"]).all()

@@ -11,15 +11,16 @@ OUT="/tmp/prof_$TAG"
 rm -rf "$OUT"; mkdir -p "$OUT" "$FINAL"
 export TMPDIR=/tmp
 cd /tmp
-CMD="python $ROOT/bench.py --steps 1 --warmup 0 --n-fps $NFPS --no-cpu"
+CMD="python $ROOT/bench.py --steps 1 --warmup 0 --n-fps $NFPS --no-cpu --shards 0 --k1-rows $NFPS"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o bench -- $CMD > "$OUT/bench_trace.log" 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o bench -- $CMD > "$OUT/bench_pmc_fetch.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o bench -- $CMD > "$OUT/bench_pmc_write.log" 2>&1
 for f in "$OUT"/*.log; do grep -m1 metric "$f" | cut -c1-200; done
 find "$OUT" -name "*.csv" | head -50
-python - "$OUT" <<'PY'
+python - "$OUT" "$NFPS" <<'PY'
 import csv, sys, glob, collections, os
 out = sys.argv[1]
+rec = {}
 for f in glob.glob(out + "/trace/**/*kernel_stats.csv", recursive=True):
     print("== kernel stats", f)
     print(open(f).read()[:3000])
@@ -35,8 +36,18 @@ for name in ("pmc_fetch", "pmc_write"):
             for (k, c), (n, v) in sorted(agg.items()):
                 line = f"{k:60s} {c:12s} dispatches={n:6d} total={v:.1f} per_dispatch={v/max(n,1):.1f}"
                 print(line); w.write(line + "\n")
+                if "k_tree_insert" in k:
+                    rec["tree_" + ("fetch" if c == "FETCH_SIZE" else "write") + "_kb_total"] = v
+                    rec["tree_launches"] = n
+                if "k_arr_vec<16, true>" in k:
+                    rec["k1_" + ("fetch" if c == "FETCH_SIZE" else "write") + "_kb_per_dispatch"] = v / max(n, 1)
+import json
+rec["n_fps"] = int(sys.argv[2])
+rec["note"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), raw KB as reported; FETCH_SIZE must be doubled on gfx950 (MI355X_MICROARCH.md)"
+open(os.path.join(out, "pmc_latest.json"), "w").write(json.dumps(rec, indent=1))
+print(rec)
 PY
 
-cp "$OUT"/*.log "$OUT"/*_summary.txt "$FINAL"/ 2>/dev/null
+cp "$OUT"/*.log "$OUT"/*_summary.txt "$OUT"/pmc_latest.json "$FINAL"/ 2>/dev/null
 for f in $(find "$OUT/trace" -name "*kernel_stats.csv"); do cp "$f" "$FINAL/kernel_stats.csv"; done
 ls -la "$FINAL"
