@@ -238,6 +238,40 @@ __device__ __forceinline__ void block_sum(const KC& k, int& red_slot, u64 (&v)[N
     }
 }
 
+// The hot-path reduction: one dot product (64-bit only when it can exceed 32 bits) and up to
+// 1 + MAXFAST popcounts (always < 2^14), one barrier.  Results are wave-uniform.
+__device__ __forceinline__ void block_sum_fused(const KC& k, int& red_slot, bool wide_dot, u64& dot,
+                                                uint32_t (&pc)[1 + MAXFAST], int npc) {
+    LA u64* b64 = lds<u64>(k.L, k.o.red) + red_slot * TW * NRED;
+    LA uint32_t* b32 = lds<uint32_t>(k.L, k.o.red32) + red_slot * TW * NRED;
+    red_slot ^= 1;
+    const int w = threadIdx.x >> 6;
+    const bool lane0 = (threadIdx.x & 63) == 0;
+    const u64 d = wide_dot ? wsum64(dot) : (u64)wsum32((uint32_t)dot);
+    if (lane0) b64[w * NRED] = d;
+#pragma unroll
+    for (int i = 0; i < 1 + MAXFAST; ++i) {
+        if (i < npc) {
+            const uint32_t t = wsum32(pc[i]);
+            if (lane0) b32[w * NRED + i] = t;
+        }
+    }
+    __syncthreads();
+    u64 a = 0;
+#pragma unroll
+    for (int q = 0; q < TW; ++q) a += b64[q * NRED];
+    dot = uni64(a);
+#pragma unroll
+    for (int i = 0; i < 1 + MAXFAST; ++i) {
+        if (i < npc) {
+            uint32_t t = 0;
+#pragma unroll
+            for (int q = 0; q < TW; ++q) t += b32[q * NRED + i];
+            pc[i] = uni(t);
+        }
+    }
+}
+
 // ---- cluster-feature access: 8 consecutive features -----------------------------------
 __device__ __forceinline__ void cf_load8(const KC& k, uint32_t slotw, int b, uint32_t v[8]) {
     const uint32_t tier = slotw >> 30;
@@ -794,24 +828,25 @@ __device__ __forceinline__ void update_tracker_slow(const KC& k, const Elem& el,
 }
 
 // one tree per workgroup
+template <bool PROF>
 __global__ __launch_bounds__(TB) void k_tree_insert(TreeDev* trees) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     TreeDev* T = trees + blockIdx.x;
     KC k;
     k.cent = T->node_cent; k.card = T->node_card; k.link = T->node_link; k.rm = T->node_rm; k.hdr = T->node_hdr;
     k.scratch = T->scratch_cent; k.cf8 = T->cf8; k.cf16 = T->cf16; k.cf32 = T->cf32;
-    k.bufs = T->bufs; k.width = T->width;
-    k.F = T->F; k.nb = T->nbytes; k.RB = T->RB; k.RBc = k.RB / 16; k.RBS = k.RB + 16;
-    k.bf = (uint32_t)T->bf; k.rows = k.bf + 1;
-    k.crit = T->crit; k.tol_len = T->tol_len; k.thr = T->thr; k.tolerance = T->tolerance; k.tol = T->tol_table;
-    k.use_rc = T->use_root_cache != 0;
+    k.bufs = T->bufs; k.width = (int)uni((uint32_t)T->width);
+    k.F = (int)uni((uint32_t)T->F); k.nb = (int)uni((uint32_t)T->nbytes); k.RB = (int)uni((uint32_t)T->RB); k.RBc = k.RB / 16; k.RBS = k.RB + 16;
+    k.bf = uni((uint32_t)T->bf); k.rows = k.bf + 1;
+    k.crit = (int)uni((uint32_t)T->crit); k.tol_len = (int)uni((uint32_t)T->tol_len); k.thr = T->thr; k.tolerance = T->tolerance; k.tol = T->tol_table;
+    k.use_rc = uni((uint32_t)T->use_root_cache) != 0;
     k.L = (LA unsigned char*)smem_raw;
     k.o = smem_layout((int)k.bf, k.RB, k.use_rc);
     const uint8_t* in_rows = T->rows;
     const long long row_stride = T->row_stride;
     const long long n_elems = T->n_elems;
     uint32_t* out_leaf = T->out_leaf;
-    const uint32_t cap_nodes = T->cap_nodes, cap8 = T->cap8, cap16 = T->cap16, cap32 = T->cap32;
+    const uint32_t cap_nodes = uni(T->cap_nodes), cap8 = uni(T->cap8), cap16 = uni(T->cap16), cap32 = uni(T->cap32);
     const bool bufmode = k.bufs != nullptr;
     const int tid = threadIdx.x;
     const int nb = k.nb;
@@ -827,21 +862,36 @@ __global__ __launch_bounds__(TB) void k_tree_insert(TreeDev* trees) {
     LA u32x4_t* sx = lds<u32x4_t>(k.L, k.o.x);
     int red_slot = 0, cmp_par = 0;
     // allocation counters and tree roots: wave-uniform registers, updated identically by every thread
-    uint32_t cN = T->ctr[C_NODES], cI = T->ctr[C_IDS], c8 = T->ctr[C_N8], c16 = T->ctr[C_N16], c32 = T->ctr[C_N32];
-    uint32_t cRoot = T->ctr[C_ROOT], cFirst = T->ctr[C_FIRST_LEAF], cDepth = T->ctr[C_DEPTH];
+    uint32_t cN = uni(T->ctr[C_NODES]), cI = uni(T->ctr[C_IDS]), c8 = uni(T->ctr[C_N8]), c16 = uni(T->ctr[C_N16]);
+    uint32_t c32 = uni(T->ctr[C_N32]), cRoot = uni(T->ctr[C_ROOT]), cFirst = uni(T->ctr[C_FIRST_LEAF]);
+    uint32_t cDepth = uni(T->ctr[C_DEPTH]);
     if (tid < 8) stats[tid] = T->stats[tid];
     for (int ch = tid; ch < k.RBc; ch += TB) sx[ch] = (u32x4_t)(0);  // padding bytes stay zero
     __syncthreads();
     bool root_dirty = true;  // root length / LDS mirror must be (re)loaded
     uint32_t root_len = 0, root_leaf = 1;
     u64 ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    u64 tmark = __builtin_amdgcn_s_memtime();
-#define PHASE(i) do { const u64 _n = __builtin_amdgcn_s_memtime(); ph[i] += _n - tmark; tmark = _n; } while (0)
+    u64 tmark = PROF ? __builtin_amdgcn_s_memtime() : 0;
+#define PHASE(i) do { if constexpr (PROF) { const u64 _n = __builtin_amdgcn_s_memtime(); ph[i] += _n - tmark; tmark = _n; } } while (0)
+
+    // software prefetch of the next fingerprint row (aligned rows of <= 4 KiB)
+    const bool pf_ok = !bufmode && n_elems > 0 && ((((uintptr_t)in_rows) | (uintptr_t)row_stride) & 15) == 0 &&
+                       (nb & 15) == 0 && k.RBc <= TB;
+    u32x4_t pf = (u32x4_t)(0);
+    if (pf_ok && tid < k.RBc) pf = ldg<u32x4_t>(in_rows + (size_t)tid * 16);
 
     long long e = 0;
     int stop = STOP_DONE;
     for (; e < n_elems; ++e) {
-        __syncthreads();
+        // Elements meet here.  When the root is mirrored in LDS the first global read of the next
+        // insertion (level 1) sits behind the full barrier that ends the root compare, so this
+        // barrier only has to order LDS traffic: the previous insertion's HBM stores keep draining
+        // underneath the root compare instead of being waited for here.
+        if (root_dirty || !use_rc) {
+            __syncthreads();
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
         // ---- capacity for the worst case of one insertion -------------------------------
         {
             const uint32_t depth = cDepth;
@@ -864,13 +914,17 @@ __global__ __launch_bounds__(TB) void k_tree_insert(TreeDev* trees) {
         // ---- element: packed centroid into LDS, n, moments ------------------------------
         if (!bufmode) {
             const uint8_t* row = in_rows + e * row_stride;
-            if ((((uintptr_t)row) & 15) == 0 && (nb & 15) == 0) {
+            if (pf_ok) {
+                // this row was requested while the previous element was being inserted
+                if (tid < k.RBc) sx[tid] = pf;
+                if (e + 1 < n_elems && tid < k.RBc) pf = ldg<u32x4_t>(row + row_stride + (size_t)tid * 16);
+            } else if ((((uintptr_t)row) & 15) == 0 && (nb & 15) == 0) {
                 for (int ch = tid; ch < k.RBc; ch += TB) sx[ch] = ldg<u32x4_t>(row + (size_t)ch * 16);
             } else {
                 for (int b = tid; b < nb; b += TB) lds<uint8_t>(k.L, k.o.x)[b] = ldg<uint8_t>(row + b);
             }
             el.nS = 1;
-            __syncthreads();
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // orders the LDS row only
             el.pcx = lds_vec_popcount(k, k.o.x);
             el.s1S = el.pcx;
             el.s2S = el.pcx;
@@ -989,13 +1043,15 @@ __global__ __launch_bounds__(TB) void k_tree_insert(TreeDev* trees) {
             // ---- one fused pass: leaf dot product, speculative merged CF + centroid, and
             //      every ancestor's CF += element with its new centroid; one reduction ----
             const bool fast = nb <= TB;  // one byte-group (8 features) per thread
-            u64 red[NRED];
+            u64 dot = 0;
+            uint32_t pcs[1 + MAXFAST];  // [0] merged leaf centroid popcount, [1+q] ancestor q's
 #pragma unroll
-            for (int i = 0; i < NRED; ++i) red[i] = 0;
+            for (int i = 0; i < 1 + MAXFAST; ++i) pcs[i] = 0;
             uint32_t xs[8], vL[8], vT[MAXFAST][8], byteL = 0, byteT[MAXFAST];
             const int b0 = tid;
             const bool act = fast && b0 < nb;
             const int DT = D < MAXFAST ? D : MAXFAST;  // ancestors handled here
+            const bool wide_dot = bufmode || (slotT >> 30) == 2;
 #pragma unroll
             for (int q = 0; q < MAXFAST; ++q) byteT[q] = 0;
             if (fast) {
@@ -1005,24 +1061,26 @@ __global__ __launch_bounds__(TB) void k_tree_insert(TreeDev* trees) {
 #pragma unroll
                     for (int q = 0; q < MAXFAST; ++q)
                         if (q < DT) cf32_load8(k, tslot[q], b0, vT[q]);
-                    uint32_t dot32 = 0;
-                    u64 dot = 0;
+                    if (wide_dot) {
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        dot += (u64)vL[q] * xs[q];
-                        dot32 += vL[q] * xs[q];
-                        vL[q] += xs[q];
+                        for (int q = 0; q < 8; ++q) dot += (u64)vL[q] * xs[q];
+                    } else {
+                        uint32_t d32 = 0;
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) d32 += vL[q] * xs[q];
+                        dot = d32;
                     }
-                    red[0] = bufmode ? dot : (u64)dot32;  // fingerprint bits are 0/1: no overflow in 32 bits
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) vL[q] += xs[q];
                     byteL = centroid_byte(vL, new_n);
-                    red[1] = __popc(byteL);
+                    pcs[0] = __popc(byteL);
 #pragma unroll
                     for (int q = 0; q < MAXFAST; ++q) {
                         if (q < DT) {
 #pragma unroll
                             for (int z = 0; z < 8; ++z) vT[q][z] += xs[z];
                             byteT[q] = centroid_byte(vT[q], (u64)tn[q] + el.nS);
-                            red[2 + q] = __popc(byteT[q]);
+                            pcs[1 + q] = __popc(byteT[q]);
                         }
                     }
                 }
@@ -1032,14 +1090,14 @@ __global__ __launch_bounds__(TB) void k_tree_insert(TreeDev* trees) {
                     cf_load8(k, slotT, b, v);
                     elem_cols(k, el, b, x8);
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) red[0] += (u64)v[q] * x8[q];
+                    for (int q = 0; q < 8; ++q) dot += (u64)v[q] * x8[q];
                 }
             }
             PHASE(2);
-            block_sum<NRED>(k, red_slot, red);
+            block_sum_fused(k, red_slot, wide_dot || !fast, dot, pcs, fast ? 1 + DT : 0);
             PHASE(3);
             const u64 s1n = s1T + el.s1S;
-            const u64 s2n = s2T + 2ull * red[0] + el.s2S;
+            const u64 s2n = s2T + 2ull * dot + el.s2S;
             const bool accept = merge_accept(k, el, red_slot, slotT, nT, s1T, s2T, new_n, s1n, s2n);
             const size_t leafm = (size_t)leafnode * k.rows;
             if (accept) {
@@ -1051,7 +1109,7 @@ __global__ __launch_bounds__(TB) void k_tree_insert(TreeDev* trees) {
                     slotN = (new_tier << 30) | (new_tier == 1 ? c16++ : c32++);
                 }
                 uint8_t* crow = k.cent + (leafm + jl) * (size_t)k.RB;
-                u64 card = red[1];
+                u64 card = pcs[0];
                 if (fast) {
                     if (act) {
                         cf_store8(k, slotN, b0, vL);
@@ -1124,8 +1182,8 @@ __global__ __launch_bounds__(TB) void k_tree_insert(TreeDev* trees) {
                             }
                             if (tid == 0) {
                                 stg<uint32_t>((uint8_t*)(k.rm + pm) + 4, (uint32_t)n_new);
-                                stg<uint32_t>(k.card + pm, (uint32_t)red[2 + q]);
-                                if (q == 0 && use_rc) lds<uint32_t>(k.L, k.o.rc_card)[jp] = (uint32_t)red[2 + q];
+                                stg<uint32_t>(k.card + pm, pcs[1 + q]);
+                                if (q == 0 && use_rc) lds<uint32_t>(k.L, k.o.rc_card)[jp] = pcs[1 + q];
                             }
                         }
                     }
@@ -1197,7 +1255,7 @@ __global__ __launch_bounds__(TB) void k_tree_insert(TreeDev* trees) {
     if (tid == 0) {
         T->processed = e;
         T->stop_reason = stop;
-        for (int i = 0; i < 8; ++i) T->phase[i] += ph[i];
+        if constexpr (PROF) for (int i = 0; i < 8; ++i) T->phase[i] += ph[i];
     }
 #undef PHASE
 }
@@ -1366,7 +1424,10 @@ int configure(bbh_tree* t, int32_t bf, int32_t n_features) {
     h.scratch_cent = nullptr;
     BB_HIP(hipMalloc(&h.scratch_cent, ((size_t)bf + 1) * h.RB));
     if (t->lds > 48 * 1024)
-        BB_HIP(hipFuncSetAttribute((const void*)k_tree_insert, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->lds));
+    {
+        BB_HIP(hipFuncSetAttribute((const void*)k_tree_insert<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->lds));
+        BB_HIP(hipFuncSetAttribute((const void*)k_tree_insert<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->lds));
+    }
     return BBH_OK;
 }
 
@@ -1420,7 +1481,9 @@ int run_insert_multi(std::vector<Job>& jobs, hipStream_t s) {
         if (e != hipSuccess) { rc = bb::fail(BBH_ERR_HIP, "H2D: %s", hipGetErrorString(e)); break; }
         {
             bb::ProfScope ps("tree_insert", s);
-            hipLaunchKernelGGL(k_tree_insert, dim3((unsigned)active.size()), dim3(TB), lds, s, dptr);
+            static const bool prof_phases = getenv("BBHIP_PHASES") != nullptr;
+            if (prof_phases) hipLaunchKernelGGL(k_tree_insert<true>, dim3((unsigned)active.size()), dim3(TB), lds, s, dptr);
+            else hipLaunchKernelGGL(k_tree_insert<false>, dim3((unsigned)active.size()), dim3(TB), lds, s, dptr);
             e = hipGetLastError();
         }
         if (e == hipSuccess) e = hipMemcpyAsync(harr.data(), dptr, active.size() * sizeof(TreeDev), hipMemcpyDeviceToHost, s);
