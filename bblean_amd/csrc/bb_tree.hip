@@ -55,6 +55,7 @@ enum StopReason : int32_t {
     STOP_CF32 = 5,
     STOP_DEPTH = 6,
     STOP_RANGE = 7,  // n_samples would exceed 2^32-1
+    STOP_GATE = 8,   // a gate node would have to split inside a concurrent batch (admission bug)
 };
 
 enum Ctr : int { C_NODES = 0, C_IDS, C_N8, C_N16, C_N32, C_ROOT, C_FIRST_LEAF, C_DEPTH, C_COUNT };
@@ -63,7 +64,7 @@ struct __attribute__((aligned(16))) RowMeta {
     uint32_t sub;   // BitFeature id (leaf rows; NONE for tracking rows)
     uint32_t n;     // n_samples
     uint32_t slot;  // tier << 30 | index into cf8/cf16/cf32
-    uint32_t pad;
+    uint32_t pad;   // tracking rows: flip distance + 0 = unknown (see k_fd), else unused
     unsigned long long s1;  // sum(ls)      (leaf rows)
     unsigned long long s2;  // sum(ls^2)    (leaf rows)
 };
@@ -631,12 +632,32 @@ __device__ __forceinline__ bool merge_accept(const KC& k, const Elem& el, int& r
     }
 }
 
+// Allocation of ids / slots / nodes.  Single-tree launches own the tree: the counters are
+// wave-uniform registers.  In SUB (concurrent gates of one tree) mode the counters live in the
+// TreeDev and are bumped with one device-scope atomic by thread 0, broadcast through LDS.
+template <bool SUB>
+__device__ __forceinline__ uint32_t alloc_n(const KC& k, uint32_t& reg, uint32_t* gctr, uint32_t cnt, int bc_slot) {
+    if constexpr (!SUB) {
+        const uint32_t r = reg;
+        reg += cnt;
+        return r;
+    } else {
+        LA uint32_t* bc = lds<uint32_t>(k.L, k.o.bc);
+        if (threadIdx.x == 0) bc[bc_slot] = atomicAdd(gctr, cnt);
+        __syncthreads();
+        const uint32_t r = uni(bc[bc_slot]);
+        __syncthreads();
+        return r;
+    }
+}
+
 // ---- _split_node (bitbirch.py:162-211) -------------------------------------------------
 // Splits node `nd` (len = bf+1 rows).  Leaves the two tracking BitFeatures' centroids in
 // LDS (o.cA / o.cB) and publishes through bc: [0]=node1 [3]=cardA [4]=cardB [7]=nA [8]=nB
 // [9]=slotA [10]=slotB [11]=n overflow flag.
+template <bool SUB>
 __device__ __forceinline__ void split_node(const KC& k, int& red_slot, int& cmp_par, uint32_t nd, uint32_t& cN,
-                                           uint32_t& c32, uint32_t& cFirst) {
+                                           uint32_t& c32, uint32_t& cFirst, uint32_t* gctr) {
     const int tid = threadIdx.x;
     const uint32_t rows = k.rows;
     const size_t meta = (size_t)nd * rows;
@@ -717,12 +738,14 @@ __device__ __forceinline__ void split_node(const KC& k, int& red_slot, int& cmp_
     }
     // 6. ids for the new node and the two tracking BitFeatures (always cf32): every thread
     //    keeps the (uniform) allocation counters in registers
-    const uint32_t node1 = cN++;
-    const uint32_t slotA_i = c32, slotB_i = c32 + 1;
-    c32 += 2;
+    const uint32_t node1 = alloc_n<SUB>(k, cN, gctr + C_NODES, 1, 14);
+    const uint32_t slotA_i = alloc_n<SUB>(k, c32, gctr + C_N32, 2, 15), slotB_i = slotA_i + 1;
     const u32x4_t hold = ldg<u32x4_t>(k.hdr + nd);  // {len, leaf, prev, next}
     const uint32_t was_leaf = uni(hold.y), prev_leaf = uni(hold.z);
-    if (was_leaf && prev_leaf == NONE) cFirst = node1;
+    if (was_leaf && prev_leaf == NONE) {
+        if constexpr (SUB) { if (tid == 0) stg<uint32_t>(gctr + C_FIRST_LEAF, node1); }
+        else cFirst = node1;
+    }
     // 7a. stage all centroid rows (kept rows are compacted in place afterwards)
     for (uint32_t i = tid; i < m * (uint32_t)k.RBc; i += TB)
         stg<u32x4_t>(k.scratch + (size_t)i * 16, ldg<u32x4_t>(cent + (size_t)i * 16));
@@ -734,17 +757,20 @@ __device__ __forceinline__ void split_node(const KC& k, int& red_slot, int& cmp_
         bc[0] = node1;
         bc[9] = slotA_i;
         bc[10] = slotB_i;
-        u32x4_t h = hold, h1;
+        // word-granular header writes: a node's `next` word is only ever written by the split of
+        // the node that follows it in the chain, every other word only by its own subtree, so
+        // concurrent gates never race on the leaf chain
+        const u32x4_t h = hold;
+        u32x4_t h1;
         h1.x = bc[5]; h1.y = h.y; h1.z = NONE; h1.w = NONE;
-        h.x = bc[6];
         if (h.y) {
             h1.z = h.z;
             if (h.z != NONE) stg<uint32_t>((uint8_t*)(k.hdr + h.z) + 12, node1);
             h1.w = nd;
-            h.z = node1;
         }
         stg<u32x4_t>(k.hdr + node1, h1);
-        stg<u32x4_t>(k.hdr + nd, h);
+        stg<uint32_t>((uint8_t*)(k.hdr + nd), bc[6]);
+        if (h.y) stg<uint32_t>((uint8_t*)(k.hdr + nd) + 8, node1);
     }
     // 7b. distribute rows in their original order
     {
@@ -823,15 +849,18 @@ __device__ __forceinline__ void update_tracker_slow(const KC& k, const Elem& el,
     if (n_new > 0xFFFFFFFFull) stop = STOP_RANGE;
     if (tid == 0) {
         stg<uint32_t>((uint8_t*)(k.rm + pm) + 4, (uint32_t)n_new);
+        stg<uint32_t>((uint8_t*)(k.rm + pm) + 12, 0u);  // flip distance now stale
         stg<uint32_t>(k.card + pm, (uint32_t)cc[0]);
     }
 }
 
 // one tree per workgroup
-template <bool PROF>
-__global__ __launch_bounds__(TB) void k_tree_insert(TreeDev* trees) {
+template <bool PROF, bool SUB>
+__global__ __launch_bounds__(TB) void k_tree_insert(TreeDev* trees, const uint32_t* gate_nodes, const uint32_t* gate_off,
+                                                    const uint32_t* gate_elems) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    TreeDev* T = trees + blockIdx.x;
+    TreeDev* T = SUB ? trees : trees + blockIdx.x;
+    uint32_t* gctr = T->ctr;
     KC k;
     k.cent = T->node_cent; k.card = T->node_card; k.link = T->node_link; k.rm = T->node_rm; k.hdr = T->node_hdr;
     k.scratch = T->scratch_cent; k.cf8 = T->cf8; k.cf16 = T->cf16; k.cf32 = T->cf32;
@@ -844,7 +873,8 @@ __global__ __launch_bounds__(TB) void k_tree_insert(TreeDev* trees) {
     k.o = smem_layout((int)k.bf, k.RB, k.use_rc);
     const uint8_t* in_rows = T->rows;
     const long long row_stride = T->row_stride;
-    const long long n_elems = T->n_elems;
+    const uint32_t g_off = SUB ? uni(gate_off[blockIdx.x]) : 0u;
+    const long long n_elems = SUB ? (long long)(uni(gate_off[blockIdx.x + 1]) - g_off) : T->n_elems;
     uint32_t* out_leaf = T->out_leaf;
     const uint32_t cap_nodes = uni(T->cap_nodes), cap8 = uni(T->cap8), cap16 = uni(T->cap16), cap32 = uni(T->cap32);
     const bool bufmode = k.bufs != nullptr;
@@ -863,9 +893,9 @@ __global__ __launch_bounds__(TB) void k_tree_insert(TreeDev* trees) {
     int red_slot = 0, cmp_par = 0;
     // allocation counters and tree roots: wave-uniform registers, updated identically by every thread
     uint32_t cN = uni(T->ctr[C_NODES]), cI = uni(T->ctr[C_IDS]), c8 = uni(T->ctr[C_N8]), c16 = uni(T->ctr[C_N16]);
-    uint32_t c32 = uni(T->ctr[C_N32]), cRoot = uni(T->ctr[C_ROOT]), cFirst = uni(T->ctr[C_FIRST_LEAF]);
+    uint32_t c32 = uni(T->ctr[C_N32]), cRoot = SUB ? uni(gate_nodes[blockIdx.x]) : uni(T->ctr[C_ROOT]), cFirst = uni(T->ctr[C_FIRST_LEAF]);
     uint32_t cDepth = uni(T->ctr[C_DEPTH]);
-    if (tid < 8) stats[tid] = T->stats[tid];
+    if (tid < 8) stats[tid] = SUB ? 0ull : T->stats[tid];
     for (int ch = tid; ch < k.RBc; ch += TB) sx[ch] = (u32x4_t)(0);  // padding bytes stay zero
     __syncthreads();
     bool root_dirty = true;  // root length / LDS mirror must be (re)loaded
@@ -878,7 +908,7 @@ __global__ __launch_bounds__(TB) void k_tree_insert(TreeDev* trees) {
     const bool pf_ok = !bufmode && n_elems > 0 && ((((uintptr_t)in_rows) | (uintptr_t)row_stride) & 15) == 0 &&
                        (nb & 15) == 0 && k.RBc <= TB;
     u32x4_t pf = (u32x4_t)(0);
-    if (pf_ok && tid < k.RBc) pf = ldg<u32x4_t>(in_rows + (size_t)tid * 16);
+    if (pf_ok && tid < k.RBc) pf = ldg<u32x4_t>(in_rows + (SUB ? (size_t)uni(gate_elems[g_off]) * (size_t)row_stride : 0) + (size_t)tid * 16);
 
     long long e = 0;
     int stop = STOP_DONE;
@@ -893,7 +923,7 @@ __global__ __launch_bounds__(TB) void k_tree_insert(TreeDev* trees) {
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
         // ---- capacity for the worst case of one insertion -------------------------------
-        {
+        if constexpr (!SUB) {
             const uint32_t depth = cDepth;
             if (depth + 2 >= (uint32_t)MAXD) { stop = STOP_DEPTH; break; }
             if (cN + depth + 2 > cap_nodes) { stop = STOP_NODES; break; }
@@ -910,14 +940,18 @@ __global__ __launch_bounds__(TB) void k_tree_insert(TreeDev* trees) {
             root_dirty = false;
         }
         Elem el;
-        el.idx = e;
+        const long long eidx = SUB ? (long long)uni(gate_elems[g_off + e]) : e;  // position in the input array
+        el.idx = eidx;
         // ---- element: packed centroid into LDS, n, moments ------------------------------
         if (!bufmode) {
-            const uint8_t* row = in_rows + e * row_stride;
+            const uint8_t* row = in_rows + eidx * row_stride;
             if (pf_ok) {
                 // this row was requested while the previous element was being inserted
                 if (tid < k.RBc) sx[tid] = pf;
-                if (e + 1 < n_elems && tid < k.RBc) pf = ldg<u32x4_t>(row + row_stride + (size_t)tid * 16);
+                if (e + 1 < n_elems && tid < k.RBc) {
+                    const long long nidx = SUB ? (long long)uni(gate_elems[g_off + e + 1]) : e + 1;
+                    pf = ldg<u32x4_t>(in_rows + nidx * row_stride + (size_t)tid * 16);
+                }
             } else if ((((uintptr_t)row) & 15) == 0 && (nb & 15) == 0) {
                 for (int ch = tid; ch < k.RBc; ch += TB) sx[ch] = ldg<u32x4_t>(row + (size_t)ch * 16);
             } else {
@@ -930,7 +964,7 @@ __global__ __launch_bounds__(TB) void k_tree_insert(TreeDev* trees) {
             el.s2S = el.pcx;
         } else {
             u64 nraw;
-            const size_t ncol = (size_t)e * ((size_t)k.F + 1) + (size_t)k.F;
+            const size_t ncol = (size_t)eidx * ((size_t)k.F + 1) + (size_t)k.F;
             switch (k.width) {
                 case 1: nraw = ldg<uint8_t>(k.bufs + ncol); break;
                 case 2: nraw = ldg<uint16_t>(k.bufs + 2 * ncol); break;
@@ -965,8 +999,10 @@ __global__ __launch_bounds__(TB) void k_tree_insert(TreeDev* trees) {
         if (root_len == 0) {
             // ---- very first element of an empty tree: row 0 of the root leaf -------------
             const uint32_t tier = tier_for(el.nS);
-            const uint32_t s = cI++;
-            const uint32_t slotw = (tier << 30) | (tier == 0 ? c8++ : (tier == 1 ? c16++ : c32++));
+            const uint32_t s = alloc_n<SUB>(k, cI, gctr + C_IDS, 1, 14);
+            const uint32_t slotw = (tier << 30) | (tier == 0 ? alloc_n<SUB>(k, c8, gctr + C_N8, 1, 15)
+                                                 : (tier == 1 ? alloc_n<SUB>(k, c16, gctr + C_N16, 1, 15)
+                                                              : alloc_n<SUB>(k, c32, gctr + C_N32, 1, 15)));
             if (tid == 0) {
                 stg<uint32_t>(k.hdr + root, 1u);
                 stats[3]++;
@@ -1106,7 +1142,8 @@ __global__ __launch_bounds__(TB) void k_tree_insert(TreeDev* trees) {
                 const uint32_t new_tier = tier_for(new_n) > old_tier ? tier_for(new_n) : old_tier;
                 uint32_t slotN = slotT;
                 if (new_tier != old_tier) {
-                    slotN = (new_tier << 30) | (new_tier == 1 ? c16++ : c32++);
+                    slotN = (new_tier << 30) | (new_tier == 1 ? alloc_n<SUB>(k, c16, gctr + C_N16, 1, 15)
+                                                              : alloc_n<SUB>(k, c32, gctr + C_N32, 1, 15));
                 }
                 uint8_t* crow = k.cent + (leafm + jl) * (size_t)k.RB;
                 u64 card = pcs[0];
@@ -1145,8 +1182,10 @@ __global__ __launch_bounds__(TB) void k_tree_insert(TreeDev* trees) {
             } else {
                 // append_subcluster (bitbirch.py:284-287): new leaf BitFeature
                 const uint32_t tier = tier_for(el.nS);
-                const uint32_t s = cI++;
-                const uint32_t slotw = (tier << 30) | (tier == 0 ? c8++ : (tier == 1 ? c16++ : c32++));
+                const uint32_t s = alloc_n<SUB>(k, cI, gctr + C_IDS, 1, 14);
+                const uint32_t slotw = (tier << 30) | (tier == 0 ? alloc_n<SUB>(k, c8, gctr + C_N8, 1, 15)
+                                                     : (tier == 1 ? alloc_n<SUB>(k, c16, gctr + C_N16, 1, 15)
+                                                                  : alloc_n<SUB>(k, c32, gctr + C_N32, 1, 15)));
                 if (tid == 0) {
                     stg<uint32_t>(k.hdr + leafnode, leaflen + 1);
                     stats[3]++;
@@ -1182,6 +1221,7 @@ __global__ __launch_bounds__(TB) void k_tree_insert(TreeDev* trees) {
                             }
                             if (tid == 0) {
                                 stg<uint32_t>((uint8_t*)(k.rm + pm) + 4, (uint32_t)n_new);
+                                stg<uint32_t>((uint8_t*)(k.rm + pm) + 12, 0u);  // flip distance now stale
                                 stg<uint32_t>(k.card + pm, pcs[1 + q]);
                                 if (q == 0 && use_rc) lds<uint32_t>(k.L, k.o.rc_card)[jp] = pcs[1 + q];
                             }
@@ -1203,11 +1243,16 @@ __global__ __launch_bounds__(TB) void k_tree_insert(TreeDev* trees) {
             bool range_bad = false;
             while (true) {
                 const uint32_t nd = uni(path_node[lvl]);
-                split_node(k, red_slot, cmp_par, nd, cN, c32, cFirst);
+                split_node<SUB>(k, red_slot, cmp_par, nd, cN, c32, cFirst, gctr);
                 const uint32_t node1 = uni(bc[0]), cardA = uni(bc[3]), cardB = uni(bc[4]);
                 const uint32_t nA = uni(bc[7]), nB = uni(bc[8]);
                 const uint32_t slotA = (2u << 30) | uni(bc[9]), slotB = (2u << 30) | uni(bc[10]);
                 if (uni(bc[11])) { range_bad = true; break; }
+                if (SUB && lvl == 0) {  // a gate may never split inside a concurrent batch
+                    range_bad = true;
+                    stop = STOP_GATE;
+                    break;
+                }
                 if (lvl == 0) {
                     // root split: new root holding the two tracking BitFeatures
                     const uint32_t nr = cN++;
@@ -1237,25 +1282,32 @@ __global__ __launch_bounds__(TB) void k_tree_insert(TreeDev* trees) {
                 upd_levels = lvl - 1;
                 break;
             }
-            if (range_bad) { stop = STOP_RANGE; break; }
+            if (range_bad) { if (stop == STOP_DONE) stop = STOP_RANGE; break; }
             __syncthreads();
             root_dirty = true;
             for (int lv = 0; lv < upd_levels; ++lv) update_tracker_slow(k, el, red_slot, lv, stop);
         }
         PHASE(5);
         if (stop != STOP_DONE) break;
-        if (tid == 0 && out_leaf) stg<uint32_t>(out_leaf + e, out_id);
+        if (tid == 0 && out_leaf) stg<uint32_t>(out_leaf + eidx, out_id);
     }
     __syncthreads();
-    if (tid == 0) {
-        T->ctr[C_NODES] = cN; T->ctr[C_IDS] = cI; T->ctr[C_N8] = c8; T->ctr[C_N16] = c16; T->ctr[C_N32] = c32;
-        T->ctr[C_ROOT] = cRoot; T->ctr[C_FIRST_LEAF] = cFirst; T->ctr[C_DEPTH] = cDepth;
-    }
-    if (tid < 8) T->stats[tid] = stats[tid];
-    if (tid == 0) {
-        T->processed = e;
-        T->stop_reason = stop;
-        if constexpr (PROF) for (int i = 0; i < 8; ++i) T->phase[i] += ph[i];
+    if constexpr (SUB) {
+        // concurrent gates of one tree: counters were bumped atomically; fold the statistics in
+        if (tid < 7 && tid != 5 && tid != 6) atomicAdd((unsigned long long*)&T->stats[tid], (unsigned long long)stats[tid] );
+        if (tid == 5) atomicAdd((unsigned long long*)&T->stats[5], (unsigned long long)stats[5]);
+        if (tid == 0 && stop != STOP_DONE) atomicMax(&T->stop_reason, stop);
+    } else {
+        if (tid == 0) {
+            T->ctr[C_NODES] = cN; T->ctr[C_IDS] = cI; T->ctr[C_N8] = c8; T->ctr[C_N16] = c16; T->ctr[C_N32] = c32;
+            T->ctr[C_ROOT] = cRoot; T->ctr[C_FIRST_LEAF] = cFirst; T->ctr[C_DEPTH] = cDepth;
+        }
+        if (tid < 8) T->stats[tid] = stats[tid];
+        if (tid == 0) {
+            T->processed = e;
+            T->stop_reason = stop;
+            if constexpr (PROF) for (int i = 0; i < 8; ++i) T->phase[i] += ph[i];
+        }
     }
 #undef PHASE
 }
@@ -1425,8 +1477,9 @@ int configure(bbh_tree* t, int32_t bf, int32_t n_features) {
     BB_HIP(hipMalloc(&h.scratch_cent, ((size_t)bf + 1) * h.RB));
     if (t->lds > 48 * 1024)
     {
-        BB_HIP(hipFuncSetAttribute((const void*)k_tree_insert<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->lds));
-        BB_HIP(hipFuncSetAttribute((const void*)k_tree_insert<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->lds));
+        BB_HIP(hipFuncSetAttribute((const void*)k_tree_insert<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->lds));
+        BB_HIP(hipFuncSetAttribute((const void*)k_tree_insert<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->lds));
+        BB_HIP(hipFuncSetAttribute((const void*)k_tree_insert<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->lds));
     }
     return BBH_OK;
 }
@@ -1482,8 +1535,12 @@ int run_insert_multi(std::vector<Job>& jobs, hipStream_t s) {
         {
             bb::ProfScope ps("tree_insert", s);
             static const bool prof_phases = getenv("BBHIP_PHASES") != nullptr;
-            if (prof_phases) hipLaunchKernelGGL(k_tree_insert<true>, dim3((unsigned)active.size()), dim3(TB), lds, s, dptr);
-            else hipLaunchKernelGGL(k_tree_insert<false>, dim3((unsigned)active.size()), dim3(TB), lds, s, dptr);
+            if (prof_phases)
+                hipLaunchKernelGGL((k_tree_insert<true, false>), dim3((unsigned)active.size()), dim3(TB), lds, s, dptr,
+                                   (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
+            else
+                hipLaunchKernelGGL((k_tree_insert<false, false>), dim3((unsigned)active.size()), dim3(TB), lds, s, dptr,
+                                   (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
             e = hipGetLastError();
         }
         if (e == hipSuccess) e = hipMemcpyAsync(harr.data(), dptr, active.size() * sizeof(TreeDev), hipMemcpyDeviceToHost, s);
