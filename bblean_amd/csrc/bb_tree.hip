@@ -1312,6 +1312,139 @@ __global__ __launch_bounds__(TB) void k_tree_insert(TreeDev* trees, const uint32
 #undef PHASE
 }
 
+// =======================================================================================
+// Batch mode (exact, rollback-free): a prefix of the pending fingerprints is routed through the
+// STABLE upper levels of the tree in parallel (k_route), the host admits the longest prefix for
+// which (G1) no tracking centroid of a stable node can flip (flip distance, k_upd) and (G2) no
+// gate (leaf-parent node) can overflow, then every gate inserts its own elements sequentially
+// (k_tree_insert<.., SUB>), all gates concurrently, and the stable trackers receive their
+// commutative cluster-feature sums (k_upd).  See DESIGN.md section 6b for the argument.
+// =======================================================================================
+struct RouteRec {
+    uint32_t gate, gate_len, leaf, leaf_len, sumlen, pad;
+    uint32_t node[4], row[4], fd[4];
+};
+
+__device__ __forceinline__ KC make_kc(TreeDev* T, unsigned char* smem_raw, bool use_rc) {
+    KC k;
+    k.cent = T->node_cent; k.card = T->node_card; k.link = T->node_link; k.rm = T->node_rm; k.hdr = T->node_hdr;
+    k.scratch = T->scratch_cent; k.cf8 = T->cf8; k.cf16 = T->cf16; k.cf32 = T->cf32;
+    k.bufs = nullptr; k.width = 0;
+    k.F = (int)uni((uint32_t)T->F); k.nb = (int)uni((uint32_t)T->nbytes); k.RB = (int)uni((uint32_t)T->RB);
+    k.RBc = k.RB / 16; k.RBS = k.RB + 16;
+    k.bf = uni((uint32_t)T->bf); k.rows = k.bf + 1;
+    k.crit = 0; k.tol_len = 0; k.thr = 0; k.tolerance = 0; k.tol = nullptr;
+    k.use_rc = use_rc;
+    k.L = (LA unsigned char*)smem_raw;
+    k.o = smem_layout((int)k.bf, k.RB, use_rc);
+    return k;
+}
+
+// one workgroup per pending fingerprint: greedy descent through G stable levels + the gate
+__global__ __launch_bounds__(TB) void k_route(TreeDev* T, long long first_idx, uint32_t G, RouteRec* out) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    const KC k = make_kc(T, smem_raw, false);
+    const int tid = threadIdx.x;
+    const long long idx = first_idx + blockIdx.x;
+    const uint8_t* row = T->rows + idx * T->row_stride;
+    LA u32x4_t* sx = lds<u32x4_t>(k.L, k.o.x);
+    for (int ch = tid; ch < k.RBc; ch += TB) sx[ch] = (u32x4_t)(0);
+    __syncthreads();
+    for (int b = tid; b < k.nb; b += TB) lds<uint8_t>(k.L, k.o.x)[b] = ldg<uint8_t>(row + b);
+    __syncthreads();
+    const uint32_t pcx = lds_vec_popcount(k, k.o.x);
+    int cmp_par = 0;
+    uint32_t nd = uni(T->ctr[C_ROOT]);
+    uint32_t sumlen = 0;
+    RouteRec rec;
+    rec.pad = 0;
+#pragma unroll
+    for (int l = 0; l < 4; ++l) { rec.node[l] = NONE; rec.row[l] = 0; rec.fd[l] = 0; }
+    for (uint32_t l = 0; l <= G; ++l) {
+        uint32_t len = 0, leaf = 0;
+        const Cand best = node_best<false, false>(k, cmp_par, nd, -1, k.o.x, pcx, false, false, true, &len, &leaf);
+        const uint32_t link = uni(lds<uint32_t>(k.L, k.o.link)[cmp_par * k.rows + best.r]);
+        if (l < G) {
+            const uint32_t fd = uni(ldg<uint32_t>((const uint8_t*)(k.rm + (size_t)nd * k.rows + best.r) + 12));
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if ((uint32_t)q == l) { rec.node[q] = nd; rec.row[q] = best.r; rec.fd[q] = fd; }
+            sumlen += len;
+            nd = link;
+        } else {
+            rec.gate = nd;
+            rec.gate_len = len;
+            rec.leaf = link;
+            rec.leaf_len = uni(ldg<uint32_t>(k.hdr + link));
+        }
+    }
+    rec.sumlen = sumlen;
+    if (tid == 0) out[blockIdx.x] = rec;
+}
+
+// one workgroup per stable tracking row: CF += sum of the admitted fingerprints routed through
+// it (commutative), n += count, new centroid / popcount, and the row's flip distance
+//   fd = min over features of (2*ls >= n ? 2*ls - n + 1 : n - 2*ls)
+// = the smallest number of further single-fingerprint additions that could change any centroid
+// bit.  count == 0 just (re)computes fd.
+__global__ __launch_bounds__(TB) void k_upd(TreeDev* T, const uint32_t* u_node, const uint32_t* u_row,
+                                            const uint32_t* u_off, const uint32_t* u_elems, uint32_t* out_fd) {
+    __shared__ unsigned long long s_card[TW];
+    __shared__ uint32_t s_fd[TW];
+    const int tid = threadIdx.x;
+    const uint32_t F = (uint32_t)T->F, nb = (uint32_t)T->nbytes, RB = (uint32_t)T->RB;
+    const size_t rows = (size_t)T->bf + 1;
+    const uint32_t nd = u_node[blockIdx.x], r = u_row[blockIdx.x];
+    const uint32_t e0 = u_off[blockIdx.x], e1 = u_off[blockIdx.x + 1];
+    const size_t m = (size_t)nd * rows + r;
+    RowMeta* rm = T->node_rm + m;
+    const uint32_t slot = rm->slot & 0x3FFFFFFFu;
+    const unsigned long long n_new = (unsigned long long)rm->n + (e1 - e0);
+    uint32_t* cf = T->cf32 + (size_t)slot * F;
+    const uint8_t* in_rows = T->rows;
+    const long long stride = T->row_stride;
+    unsigned long long card = 0;
+    uint32_t fd = 0xFFFFFFFEu;
+    for (uint32_t b = tid; b < nb; b += TB) {
+        uint32_t acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (uint32_t e = e0; e < e1; ++e) {
+            const uint32_t v = in_rows[(long long)u_elems[e] * stride + b];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc[q] += (v >> (7 - q)) & 1u;
+        }
+        uint32_t byte = 0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const unsigned long long v = (unsigned long long)cf[b * 8 + q] + acc[q];
+            cf[b * 8 + q] = (uint32_t)v;
+            const bool bit = n_new <= 1 ? ((v & 0xFF) != 0) : (2ull * v >= n_new);
+            byte |= (bit ? 1u : 0u) << (7 - q);
+            const unsigned long long d = 2ull * v >= n_new ? 2ull * v - n_new + 1ull : n_new - 2ull * v;
+            const uint32_t dd = d > 0xFFFFFFFEull ? 0xFFFFFFFEu : (uint32_t)d;
+            fd = dd < fd ? dd : fd;
+        }
+        T->node_cent[m * RB + b] = (uint8_t)byte;
+        card += __popc(byte);
+    }
+    for (int o = 32; o >= 1; o >>= 1) {
+        card += (unsigned long long)__shfl_xor((long long)card, o);
+        const uint32_t of = (uint32_t)__shfl_xor((int)fd, o);
+        fd = of < fd ? of : fd;
+    }
+    if ((tid & 63) == 0) { s_card[tid >> 6] = card; s_fd[tid >> 6] = fd; }
+    __syncthreads();
+    if (tid == 0) {
+        unsigned long long c = 0;
+        uint32_t f = 0xFFFFFFFEu;
+        for (int w = 0; w < TW; ++w) { c += s_card[w]; f = s_fd[w] < f ? s_fd[w] : f; }
+        if (n_new > 0xFFFFFFFFull) atomicMax(&T->stop_reason, (int)STOP_RANGE);
+        rm->n = (uint32_t)n_new;
+        rm->pad = f;
+        T->node_card[m] = (uint32_t)c;
+        if (out_fd) out_fd[blockIdx.x] = f;
+    }
+}
+
 // ---- extraction ---------------------------------------------------------------------------
 // one workgroup per requested leaf row: BitFeature buffer [linear_sum | n] at `width` bytes
 __global__ __launch_bounds__(256) void k_gather_leaves(TreeDev* Tp, const uint32_t* nodes, const uint32_t* rowsidx,
@@ -1588,6 +1721,10 @@ int run_insert(bbh_tree* t, const uint8_t* rows_dev, int64_t row_stride, const u
     return run_insert_multi(jobs, s);
 }
 
+uint32_t clamp30(uint64_t v) { return (uint32_t)std::min<uint64_t>(0x3FFFFFFFull, v); }
+
+#include "bb_tree_batch.inc"
+
 // walk the leaf chain on the host (bitbirch.py:886-893): positions -> (node, row)
 int build_chain(bbh_tree* t) {
     if (t->chain_valid) return BBH_OK;
@@ -1623,7 +1760,6 @@ int build_chain(bbh_tree* t) {
     return BBH_OK;
 }
 
-uint32_t clamp30(uint64_t v) { return (uint32_t)std::min<uint64_t>(0x3FFFFFFFull, v); }
 
 }  // namespace
 
@@ -1710,8 +1846,11 @@ extern "C" int bbh_tree_fit_packed(bbh_tree* t, const uint8_t* rows, int64_t n, 
     BB_TRY(grow_cf(t, 2, clamp30((uint64_t)t->h.ctr[C_N32] + (uint64_t)n / std::max(1, t->h.bf / 6) + 256)));
     bb::DevOut o;
     BB_TRY(o.init(out_leaf, (size_t)n * 4));
+    const char* benv = getenv("BBHIP_BATCH");
+    const int batch = benv ? atoi(benv) : 0;
     if (bb::is_device_ptr(rows)) {
-        BB_TRY(run_insert(t, rows, row_stride, nullptr, 0, n, (uint32_t*)o.dev, s));
+        if (batch > 0) BB_TRY(run_insert_batched(t, rows, row_stride, n, (uint32_t*)o.dev, batch, s));
+        else BB_TRY(run_insert(t, rows, row_stride, nullptr, 0, n, (uint32_t*)o.dev, s));
     } else {
         // stage host rows through HBM in slabs (PCIe is outside the engine's hot loop)
         const int64_t slab = std::max<int64_t>(1, (int64_t)(1ull << 30) / row_stride);
@@ -1722,7 +1861,8 @@ extern "C" int bbh_tree_fit_packed(bbh_tree* t, const uint8_t* rows, int64_t n, 
             const int64_t m = std::min(slab, n - off);
             hipError_t e = hipMemcpyAsync(stage, rows + off * row_stride, (size_t)m * row_stride, hipMemcpyHostToDevice, s);
             if (e != hipSuccess) { rc = bb::fail(BBH_ERR_HIP, "H2D: %s", hipGetErrorString(e)); break; }
-            rc = run_insert(t, stage, row_stride, nullptr, 0, m, o.dev ? (uint32_t*)o.dev + off : nullptr, s);
+            rc = batch > 0 ? run_insert_batched(t, stage, row_stride, m, o.dev ? (uint32_t*)o.dev + off : nullptr, batch, s)
+                           : run_insert(t, stage, row_stride, nullptr, 0, m, o.dev ? (uint32_t*)o.dev + off : nullptr, s);
         }
         (void)hipStreamSynchronize(s);
         (void)hipFree(stage);
