@@ -46,6 +46,7 @@ constexpr int MAXD = 64;     // deepest tree handled
 constexpr int MAXFAST = 5;   // ancestor levels updated in the fused fast path
 constexpr int NRED = 2 + MAXFAST;
 constexpr int MAX_BF = 1023;
+constexpr int MAXM = 4;  // levels of the current root-to-leaf path mirrored in LDS
 
 enum StopReason : int32_t {
     STOP_DONE = 0,
@@ -124,11 +125,11 @@ struct Smem {
     uint32_t ctr;                 // C_COUNT u32
     uint32_t stats;               // 8 u64
     uint32_t bc;                  // 16 u32 broadcast scratch
-    uint32_t rc_cent, rc_card, rc_link;  // LDS mirror of the root node
+    uint32_t rc_cent, rc_card, rc_link;  // LDS mirrors of the nodes on the current path (MAXM levels)
     uint32_t total;
 };
 
-__host__ __device__ inline Smem smem_layout(int bf, int RB, bool root_cache) {
+__host__ __device__ inline Smem smem_layout(int bf, int RB, int nm) {
     Smem s{};
     uint32_t off = 0;
     auto take = [&](size_t bytes) {
@@ -147,10 +148,10 @@ __host__ __device__ inline Smem smem_layout(int bf, int RB, bool root_cache) {
     s.path_node = take(MAXD * 4); s.path_row = take(MAXD * 4); s.path_len = take(MAXD * 4);
     s.path_slot = take(MAXD * 4); s.path_n = take(MAXD * 4);
     s.ctr = take(C_COUNT * 4); s.stats = take(8 * 8); s.bc = take(16 * 4);
-    if (root_cache) {
-        s.rc_cent = take(m * ((size_t)RB + 16));
-        s.rc_card = take(m * 4);
-        s.rc_link = take(m * 4);
+    if (nm > 0) {
+        s.rc_cent = take((size_t)nm * m * ((size_t)RB + 16));
+        s.rc_card = take((size_t)nm * m * 4);
+        s.rc_link = take((size_t)nm * m * 4);
     }
     s.total = off;
     return s;
@@ -210,7 +211,7 @@ struct KC {
     int F, nb, RB, RBc, RBS;
     uint32_t rows, bf;
     int crit, tol_len; double thr, tolerance; const double* tol;
-    bool use_rc;
+    int nm;  // mirrored levels
     LA unsigned char* L;
     Smem o;
 };
@@ -393,7 +394,9 @@ __device__ __forceinline__ bool cand_better(uint32_t ai, uint32_t au, uint32_t a
 template <bool ROOT, bool MINMODE>
 __device__ __forceinline__ Cand node_best(const KC& k, int& cmp_par, uint32_t nd, int known_len, uint32_t vec_off,
                                           uint32_t vec_pc, bool want_counts, bool second, bool want_link,
-                                          uint32_t* out_len, uint32_t* out_leaf) {
+                                          uint32_t* out_len, uint32_t* out_leaf, uint32_t mslot = 0, bool fill = false) {
+    // ROOT: read the node from LDS mirror `mslot`; !ROOT && fill: read HBM and refresh that mirror
+    const uint32_t mrow0 = mslot * k.rows;
     const int tid = threadIdx.x, l = tid & 15, g = tid >> 4;
     const uint32_t rows = k.rows;
     cmp_par ^= 1;
@@ -422,8 +425,8 @@ __device__ __forceinline__ Cand node_best(const KC& k, int& cmp_par, uint32_t nd
                 const uint32_t r = r0 + p * 16 + g;
                 const uint32_t rc = r < last ? r : last;
                 if constexpr (ROOT) {
-                    d[p] = *(LA u32x4_t*)(k.L + k.o.rc_cent + rc * k.RBS + l * 16);
-                    cd[p] = lds<uint32_t>(k.L, k.o.rc_card)[rc];
+                    d[p] = *(LA u32x4_t*)(k.L + k.o.rc_cent + (mrow0 + rc) * k.RBS + l * 16);
+                    cd[p] = lds<uint32_t>(k.L, k.o.rc_card)[mrow0 + rc];
                 } else {
                     d[p] = ldg<u32x4_t>(k.cent + (meta + rc) * 256 + l * 16);
                     cd[p] = ldg<uint32_t>(k.card + meta + rc);
@@ -434,7 +437,21 @@ __device__ __forceinline__ Cand node_best(const KC& k, int& cmp_par, uint32_t nd
 #pragma unroll
                     for (int p = 0; p < 4; ++p) {
                         const uint32_t r = r0 + p * 16 + g;
-                        if (l == 0 && r < rows) s_link[r] = ldg<uint32_t>(k.link + meta + r);
+                        if (l == 0 && r < rows) {
+                            const uint32_t lk = ldg<uint32_t>(k.link + meta + r);
+                            s_link[r] = lk;
+                            if (fill) lds<uint32_t>(k.L, k.o.rc_link)[mrow0 + r] = lk;
+                        }
+                    }
+                }
+                if (fill) {
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) {
+                        const uint32_t r = r0 + p * 16 + g;
+                        if (r < rows) {
+                            *(LA u32x4_t*)(k.L + k.o.rc_cent + (mrow0 + r) * k.RBS + l * 16) = d[p];
+                            if (l == 0) lds<uint32_t>(k.L, k.o.rc_card)[mrow0 + r] = cd[p];
+                        }
                     }
                 }
             }
@@ -474,13 +491,13 @@ __device__ __forceinline__ Cand node_best(const KC& k, int& cmp_par, uint32_t nd
             if (r < len) {
                 for (int ch = l; ch < k.RBc; ch += 16) {
                     u32x4_t d;
-                    if constexpr (ROOT) d = *(LA u32x4_t*)(k.L + k.o.rc_cent + r * k.RBS + ch * 16);
+                    if constexpr (ROOT) d = *(LA u32x4_t*)(k.L + k.o.rc_cent + (mrow0 + r) * k.RBS + ch * 16);
                     else d = ldg<u32x4_t>(k.cent + (meta + r) * (size_t)k.RB + ch * 16);
                     part += popc4v(d & vec[ch]);
                 }
                 if (l == 0) {
                     if constexpr (ROOT) {
-                        part += lds<uint32_t>(k.L, k.o.rc_card)[r] << 16;
+                        part += lds<uint32_t>(k.L, k.o.rc_card)[mrow0 + r] << 16;
                     } else {
                         part += ldg<uint32_t>(k.card + meta + r) << 16;
                         if (want_link) s_link[r] = ldg<uint32_t>(k.link + meta + r);
@@ -537,20 +554,6 @@ __device__ __forceinline__ void node_put_row(const KC& k, uint32_t nd, uint32_t 
         b.x = (uint32_t)s1; b.y = (uint32_t)(s1 >> 32); b.z = (uint32_t)s2; b.w = (uint32_t)(s2 >> 32);
         stg<u32x4_t>((uint8_t*)(k.rm + m), a);
         stg<u32x4_t>((uint8_t*)(k.rm + m) + 16, b);
-    }
-}
-
-// copy the root node into its LDS mirror (caller provides the barriers around it)
-__device__ __forceinline__ void root_mirror_load(const KC& k, uint32_t root) {
-    const size_t meta = (size_t)root * k.rows;
-    for (uint32_t i = threadIdx.x; i < k.rows * (uint32_t)k.RBc; i += TB) {
-        const uint32_t r = i / k.RBc, ch = i % k.RBc;
-        *(LA u32x4_t*)(k.L + k.o.rc_cent + r * k.RBS + ch * 16) =
-            ldg<u32x4_t>(k.cent + (meta + r) * (size_t)k.RB + (size_t)ch * 16);
-    }
-    for (uint32_t r = threadIdx.x; r < k.rows; r += TB) {
-        lds<uint32_t>(k.L, k.o.rc_card)[r] = ldg<uint32_t>(k.card + meta + r);
-        lds<uint32_t>(k.L, k.o.rc_link)[r] = ldg<uint32_t>(k.link + meta + r);
     }
 }
 
@@ -868,9 +871,9 @@ __global__ __launch_bounds__(TB) void k_tree_insert(TreeDev* trees, const uint32
     k.F = (int)uni((uint32_t)T->F); k.nb = (int)uni((uint32_t)T->nbytes); k.RB = (int)uni((uint32_t)T->RB); k.RBc = k.RB / 16; k.RBS = k.RB + 16;
     k.bf = uni((uint32_t)T->bf); k.rows = k.bf + 1;
     k.crit = (int)uni((uint32_t)T->crit); k.tol_len = (int)uni((uint32_t)T->tol_len); k.thr = T->thr; k.tolerance = T->tolerance; k.tol = T->tol_table;
-    k.use_rc = uni((uint32_t)T->use_root_cache) != 0;
+    k.nm = (int)uni((uint32_t)T->use_root_cache);  // number of mirrored path levels
     k.L = (LA unsigned char*)smem_raw;
-    k.o = smem_layout((int)k.bf, k.RB, k.use_rc);
+    k.o = smem_layout((int)k.bf, k.RB, k.nm);
     const uint8_t* in_rows = T->rows;
     const long long row_stride = T->row_stride;
     const uint32_t g_off = SUB ? uni(gate_off[blockIdx.x]) : 0u;
@@ -881,7 +884,7 @@ __global__ __launch_bounds__(TB) void k_tree_insert(TreeDev* trees, const uint32
     const int tid = threadIdx.x;
     const int nb = k.nb;
     const uint32_t bf = k.bf;
-    const bool use_rc = k.use_rc;
+    const int nm = k.nm;
     LA u64* stats = lds<u64>(k.L, k.o.stats);
     LA uint32_t* bc = lds<uint32_t>(k.L, k.o.bc);
     LA uint32_t* path_node = lds<uint32_t>(k.L, k.o.path_node);
@@ -898,8 +901,12 @@ __global__ __launch_bounds__(TB) void k_tree_insert(TreeDev* trees, const uint32
     if (tid < 8) stats[tid] = SUB ? 0ull : T->stats[tid];
     for (int ch = tid; ch < k.RBc; ch += TB) sx[ch] = (u32x4_t)(0);  // padding bytes stay zero
     __syncthreads();
-    bool root_dirty = true;  // root length / LDS mirror must be (re)loaded
-    uint32_t root_len = 0, root_leaf = 1;
+    // LDS mirrors of the nodes on the most recent root-to-leaf path, one per level: consecutive
+    // insertions mostly revisit them (the upper levels always, and BitBIRCH trees on diverse data
+    // route whole runs of fingerprints down the same branch).  Tags are wave-uniform registers.
+    uint32_t mir_node[MAXM], mir_len[MAXM], mir_leaf[MAXM];
+#pragma unroll
+    for (int q = 0; q < MAXM; ++q) { mir_node[q] = NONE; mir_len[q] = 0; mir_leaf[q] = 0; }
     u64 ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     u64 tmark = PROF ? __builtin_amdgcn_s_memtime() : 0;
 #define PHASE(i) do { if constexpr (PROF) { const u64 _n = __builtin_amdgcn_s_memtime(); ph[i] += _n - tmark; tmark = _n; } } while (0)
@@ -917,7 +924,8 @@ __global__ __launch_bounds__(TB) void k_tree_insert(TreeDev* trees, const uint32
         // insertion (level 1) sits behind the full barrier that ends the root compare, so this
         // barrier only has to order LDS traffic: the previous insertion's HBM stores keep draining
         // underneath the root compare instead of being waited for here.
-        if (root_dirty || !use_rc) {
+        const bool root_hit = nm > 0 && mir_node[0] == cRoot;
+        if (!root_hit) {
             __syncthreads();
         } else {
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -932,13 +940,9 @@ __global__ __launch_bounds__(TB) void k_tree_insert(TreeDev* trees, const uint32
             if (c32 + 2 * (depth + 1) + 1 > cap32) { stop = STOP_CF32; break; }
         }
         const uint32_t root = cRoot;
-        if (root_dirty) {
-            if (use_rc) root_mirror_load(k, root);
-            const u32x4_t h = ldg<u32x4_t>(k.hdr + root);
-            root_len = uni(h.x);
-            root_leaf = uni(h.y);
-            root_dirty = false;
-        }
+        uint32_t root_len;
+        if (root_hit) root_len = mir_len[0];
+        else root_len = uni(ldg<uint32_t>(k.hdr + root));
         Elem el;
         const long long eidx = SUB ? (long long)uni(gate_elems[g_off + e]) : e;  // position in the input array
         el.idx = eidx;
@@ -1014,10 +1018,11 @@ __global__ __launch_bounds__(TB) void k_tree_insert(TreeDev* trees, const uint32
             }
             node_put_row(k, root, 0, k.o.x, el.pcx, slotw, s, el.nS, slotw, el.s1S, el.s2S);
             out_id = s;
-            root_dirty = true;
+#pragma unroll
+            for (int q = 0; q < MAXM; ++q) mir_node[q] = NONE;
         } else {
             // ---- greedy descent (bitbirch.py:305-357) ---------------------------------
-            uint32_t nd = root, j = 0, link = NONE, len = root_len, leaf = root_leaf;
+            uint32_t nd = root, j = 0, link = NONE, len = root_len, leaf = 0;
             int depth = 0;
             u32x4_t rm0 = (u32x4_t)(0), rm1 = (u32x4_t)(0);  // RowMeta of the chosen row
             uint32_t tslot[MAXFAST], tn[MAXFAST];             // ancestors' CF slot / n_samples (uniform)
@@ -1026,17 +1031,28 @@ __global__ __launch_bounds__(TB) void k_tree_insert(TreeDev* trees, const uint32
             bool bad = false;
             while (true) {
                 Cand best;
-                if (depth == 0 && use_rc) {
-                    best = node_best<true, false>(k, cmp_par, nd, (int)root_len, k.o.x, el.pcx, false, false, false, nullptr, nullptr);
-                } else if (depth == 0) {
-                    best = node_best<false, false>(k, cmp_par, nd, (int)root_len, k.o.x, el.pcx, false, false, true, nullptr, nullptr);
+                bool hit = false;
+#pragma unroll
+                for (int q = 0; q < MAXM; ++q)
+                    if (q < nm && depth == q && mir_node[q] == nd) { hit = true; len = mir_len[q]; leaf = mir_leaf[q]; }
+                if (hit) {
+                    best = node_best<true, false>(k, cmp_par, nd, (int)len, k.o.x, el.pcx, false, false, false, nullptr, nullptr,
+                                                  (uint32_t)depth, false);
+                    j = best.r;
+                    link = uni(lds<uint32_t>(k.L, k.o.rc_link)[(uint32_t)depth * k.rows + j]);
                 } else {
-                    best = node_best<false, false>(k, cmp_par, nd, -1, k.o.x, el.pcx, false, false, true, &len, &leaf);
+                    const bool fill = depth < nm && k.RBc == 16;
+                    best = node_best<false, false>(k, cmp_par, nd, -1, k.o.x, el.pcx, false, false, true, &len, &leaf,
+                                                   (uint32_t)depth, fill);
+                    j = best.r;
+                    link = uni(lds<uint32_t>(k.L, k.o.link)[cmp_par * k.rows + j]);
+                    if (fill) {
+#pragma unroll
+                        for (int q = 0; q < MAXM; ++q)
+                            if (depth == q) { mir_node[q] = nd; mir_len[q] = len; mir_leaf[q] = leaf; }
+                    }
                 }
-                j = best.r;
                 if (depth == 0) PHASE(6); else PHASE(7);
-                link = (depth == 0 && use_rc) ? uni(lds<uint32_t>(k.L, k.o.rc_link)[j])
-                                              : uni(lds<uint32_t>(k.L, k.o.link)[cmp_par * k.rows + j]);
                 if (depth > 0) {  // the previous level's RowMeta has arrived by now
                     const uint32_t ps = uni(rm0.z), pn = uni(rm0.y);
 #pragma unroll
@@ -1147,10 +1163,13 @@ __global__ __launch_bounds__(TB) void k_tree_insert(TreeDev* trees, const uint32
                 }
                 uint8_t* crow = k.cent + (leafm + jl) * (size_t)k.RB;
                 u64 card = pcs[0];
+                const bool leaf_mirrored = D < nm && k.RBc == 16;  // the leaf node sits in LDS mirror D
                 if (fast) {
                     if (act) {
                         cf_store8(k, slotN, b0, vL);
                         stg<uint8_t>(crow + b0, (uint8_t)byteL);
+                        if (leaf_mirrored)
+                            *(LA uint8_t*)(k.L + k.o.rc_cent + ((uint32_t)D * k.rows + jl) * k.RBS + b0) = (uint8_t)byteL;
                     }
                 } else {
                     u64 cc[1] = {0};
@@ -1176,6 +1195,10 @@ __global__ __launch_bounds__(TB) void k_tree_insert(TreeDev* trees, const uint32
                     stg<u32x4_t>((uint8_t*)(k.rm + leafm + jl) + 16, b);
                     stg<uint32_t>(k.card + leafm + jl, (uint32_t)card);
                     if (slotN != slotT) stg<uint32_t>(k.link + leafm + jl, slotN);
+                    if (leaf_mirrored) {
+                        lds<uint32_t>(k.L, k.o.rc_card)[(uint32_t)D * k.rows + jl] = (uint32_t)card;
+                        lds<uint32_t>(k.L, k.o.rc_link)[(uint32_t)D * k.rows + jl] = slotN;
+                    }
                     stats[2]++;
                 }
                 out_id = Tsub;
@@ -1200,10 +1223,20 @@ __global__ __launch_bounds__(TB) void k_tree_insert(TreeDev* trees, const uint32
                     }
                 }
                 node_put_row(k, leafnode, leaflen, k.o.x, el.pcx, slotw, s, el.nS, slotw, el.s1S, el.s2S);
+                if (D < nm && k.RBc == 16) {  // the new row also goes into the leaf's LDS mirror
+                    const uint32_t mr = (uint32_t)D * k.rows + leaflen;
+                    if (tid < k.RBc) *(LA u32x4_t*)(k.L + k.o.rc_cent + mr * k.RBS + tid * 16) = sx[tid];
+                    if (tid == 0) {
+                        lds<uint32_t>(k.L, k.o.rc_card)[mr] = el.pcx;
+                        lds<uint32_t>(k.L, k.o.rc_link)[mr] = slotw;
+                    }
+#pragma unroll
+                    for (int q = 0; q < MAXM; ++q)
+                        if (D == q) mir_len[q] = leaflen + 1;
+                }
                 out_id = s;
                 overflow = leaflen + 1 > bf;
             }
-            if (D == 0) root_dirty = true;  // the root itself is the leaf that changed
             // ---- ancestors (closest_subcluster.update, bitbirch.py:352-357) ----------------
             if (!overflow) {
                 if (fast) {
@@ -1217,20 +1250,22 @@ __global__ __launch_bounds__(TB) void k_tree_insert(TreeDev* trees, const uint32
                             if (act) {
                                 cf_store8(k, tslot[q], b0, vT[q]);
                                 stg<uint8_t>(k.cent + pm * (size_t)k.RB + b0, (uint8_t)byteT[q]);
-                                if (q == 0 && use_rc) *(LA uint8_t*)(k.L + k.o.rc_cent + jp * k.RBS + b0) = (uint8_t)byteT[q];
+                                if (q < MAXM && q < nm) *(LA uint8_t*)(k.L + k.o.rc_cent + ((uint32_t)q * k.rows + jp) * k.RBS + b0) = (uint8_t)byteT[q];
                             }
                             if (tid == 0) {
                                 stg<uint32_t>((uint8_t*)(k.rm + pm) + 4, (uint32_t)n_new);
                                 stg<uint32_t>((uint8_t*)(k.rm + pm) + 12, 0u);  // flip distance now stale
                                 stg<uint32_t>(k.card + pm, pcs[1 + q]);
-                                if (q == 0 && use_rc) lds<uint32_t>(k.L, k.o.rc_card)[jp] = pcs[1 + q];
+                                if (q < MAXM && q < nm) lds<uint32_t>(k.L, k.o.rc_card)[(uint32_t)q * k.rows + jp] = pcs[1 + q];
                             }
                         }
                     }
                 }
                 for (int lv = fast ? DT : 0; lv < D; ++lv) {  // deep trees / wide rows: one level at a time
                     update_tracker_slow(k, el, red_slot, lv, stop);
-                    if (lv == 0) root_dirty = true;
+#pragma unroll
+                    for (int q = 0; q < MAXM; ++q)
+                        if (lv == q) mir_node[q] = NONE;  // changed behind the mirror's back
                 }
             }
         }
@@ -1284,7 +1319,8 @@ __global__ __launch_bounds__(TB) void k_tree_insert(TreeDev* trees, const uint32
             }
             if (range_bad) { if (stop == STOP_DONE) stop = STOP_RANGE; break; }
             __syncthreads();
-            root_dirty = true;
+#pragma unroll
+            for (int q = 0; q < MAXM; ++q) mir_node[q] = NONE;  // the path was restructured
             for (int lv = 0; lv < upd_levels; ++lv) update_tracker_slow(k, el, red_slot, lv, stop);
         }
         PHASE(5);
@@ -1325,7 +1361,7 @@ struct RouteRec {
     uint32_t node[4], row[4], fd[4];
 };
 
-__device__ __forceinline__ KC make_kc(TreeDev* T, unsigned char* smem_raw, bool use_rc) {
+__device__ __forceinline__ KC make_kc(TreeDev* T, unsigned char* smem_raw, int nm) {
     KC k;
     k.cent = T->node_cent; k.card = T->node_card; k.link = T->node_link; k.rm = T->node_rm; k.hdr = T->node_hdr;
     k.scratch = T->scratch_cent; k.cf8 = T->cf8; k.cf16 = T->cf16; k.cf32 = T->cf32;
@@ -1334,16 +1370,16 @@ __device__ __forceinline__ KC make_kc(TreeDev* T, unsigned char* smem_raw, bool 
     k.RBc = k.RB / 16; k.RBS = k.RB + 16;
     k.bf = uni((uint32_t)T->bf); k.rows = k.bf + 1;
     k.crit = 0; k.tol_len = 0; k.thr = 0; k.tolerance = 0; k.tol = nullptr;
-    k.use_rc = use_rc;
+    k.nm = nm;
     k.L = (LA unsigned char*)smem_raw;
-    k.o = smem_layout((int)k.bf, k.RB, use_rc);
+    k.o = smem_layout((int)k.bf, k.RB, nm);
     return k;
 }
 
 // one workgroup per pending fingerprint: greedy descent through G stable levels + the gate
 __global__ __launch_bounds__(TB) void k_route(TreeDev* T, long long first_idx, uint32_t G, RouteRec* out) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    const KC k = make_kc(T, smem_raw, false);
+    const KC k = make_kc(T, smem_raw, 0);
     const int tid = threadIdx.x;
     const long long idx = first_idx + blockIdx.x;
     const uint8_t* row = T->rows + idx * T->row_stride;
@@ -1601,10 +1637,13 @@ int configure(bbh_tree* t, int32_t bf, int32_t n_features) {
     h.F = n_features;
     h.nbytes = n_features / 8;
     h.RB = (h.nbytes + 15) / 16 * 16;
-    // the LDS mirror of the root is used whenever it fits comfortably
-    const size_t with_rc = smem_layout(bf, h.RB, true).total;
-    h.use_root_cache = with_rc <= 100 * 1024 ? 1 : 0;
-    t->lds = smem_layout(bf, h.RB, h.use_root_cache != 0).total;
+    // LDS mirrors of the nodes on the current path: as many levels (<= MAXM) as fit comfortably
+    int nm = 0;
+    if (h.RB == 256)
+        for (int q = MAXM; q >= 1; --q)
+            if (smem_layout(bf, h.RB, q).total <= 100 * 1024) { nm = q; break; }
+    h.use_root_cache = nm;
+    t->lds = smem_layout(bf, h.RB, nm).total;
     if (h.scratch_cent) (void)hipFree(h.scratch_cent);
     h.scratch_cent = nullptr;
     BB_HIP(hipMalloc(&h.scratch_cent, ((size_t)bf + 1) * h.RB));
