@@ -100,3 +100,31 @@ MULTIROUND_CASES = [
     dict(name="mr_none_big", seeds=[301, 302, 303], n_per_file=1500,
          kwargs=dict(bin_size=10, threshold=0.2, branching_factor=50, refinement_before_midsection="none")),
 ]
+
+
+def clustered_dense(n: int, n_features: int, k: int, seed: int, flip: float = 0.08) -> np.ndarray:
+    r"""k dense prototypes (45-60 % bits set), every row = a random prototype with `flip` of its
+    bits toggled, in random order.  Unlike S-fake / S-ecfp the majority centroids of the upper tree
+    levels stay informative, so consecutive fingerprints are routed to DIFFERENT subtrees - the
+    workload that exercises concurrent gates in batch mode."""
+    rng = np.random.default_rng(seed)
+    dens = rng.uniform(0.45, 0.60, k)
+    protos = rng.random((k, n_features)) < dens[:, None]
+    which = rng.integers(0, k, n)
+    bits = protos[which] ^ (rng.random((n, n_features)) < flip)
+    return np.packbits(bits.astype(np.uint8), axis=1)
+
+
+def clustered_hier(n: int, n_features: int, n_super: int, k: int, seed: int,
+                   flip_cluster: float = 0.12, flip_member: float = 0.04) -> np.ndarray:
+    r"""Two-level planted structure: `n_super` super-prototypes (50 % density), k cluster prototypes
+    (a super-prototype with `flip_cluster` of its bits toggled), rows = a cluster prototype with
+    `flip_member` toggled.  Trackers that cover one super-family have bit frequencies near 85 % / 15 %:
+    informative AND far from the 50 % majority threshold, i.e. stable upper levels."""
+    rng = np.random.default_rng(seed)
+    supers = rng.random((n_super, n_features)) < 0.5
+    sup_of = rng.integers(0, n_super, k)
+    protos = supers[sup_of] ^ (rng.random((k, n_features)) < flip_cluster)
+    which = rng.integers(0, k, n)
+    bits = protos[which] ^ (rng.random((n, n_features)) < flip_member)
+    return np.packbits(bits.astype(np.uint8), axis=1)

@@ -122,3 +122,29 @@ def test_hip_tree_full_size_1M_vs_oracle():
     assert hip._engine.stats()[:7].tolist() == ora._engine.stats()[:7].tolist()
     lv_h, lv_o = hip._leaves(), ora._leaves()
     assert (lv_h["cents"] == lv_o["cents"]).all() and (lv_h["n"] == lv_o["n"]).all()
+
+
+@pytest.mark.parametrize("n,k,thr,bf,batch", [(60_000, 3000, 0.6, 50, 256), (40_000, 400, 0.7, 20, 128),
+                                             (50_000, 5000, 0.5, 50, 512)])
+def test_hip_batch_mode_concurrent_gates_vs_oracle(n, k, thr, bf, batch, monkeypatch):
+    r"""Batch mode (BBHIP_BATCH): stable-level routing in parallel, admission by flip distance and
+    gate slack, all gates of a batch inserting concurrently.  On clustered data the batches spread
+    over many gates; the result must still be the sequential one."""
+    from cases import clustered_dense
+
+    fps = clustered_dense(n, 2048, k, seed=n + k)
+    ora = BitBirch(branching_factor=bf, threshold=thr, _engine_factory=OracleEngine).fit(fps)
+    monkeypatch.setenv("BBHIP_BATCH", str(batch))
+    hip = BitBirch(branching_factor=bf, threshold=thr).fit(fps)
+    monkeypatch.delenv("BBHIP_BATCH")
+    _same(hip, ora)
+    assert hip._engine.stats()[:7].tolist() == ora._engine.stats()[:7].tolist()
+
+
+def test_hip_batch_mode_fake_vs_serial(monkeypatch):
+    fps = np.concatenate([make_fake_fingerprints(10_000, seed=300 + i) for i in range(6)])
+    ser = BitBirch(branching_factor=50, threshold=0.3).fit(fps)
+    monkeypatch.setenv("BBHIP_BATCH", "256")
+    bat = BitBirch(branching_factor=50, threshold=0.3).fit(fps)
+    monkeypatch.delenv("BBHIP_BATCH")
+    _same(bat, ser)
