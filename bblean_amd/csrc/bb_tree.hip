@@ -394,7 +394,8 @@ __device__ __forceinline__ bool cand_better(uint32_t ai, uint32_t au, uint32_t a
 template <bool ROOT, bool MINMODE>
 __device__ __forceinline__ Cand node_best(const KC& k, int& cmp_par, uint32_t nd, int known_len, uint32_t vec_off,
                                           uint32_t vec_pc, bool want_counts, bool second, bool want_link,
-                                          uint32_t* out_len, uint32_t* out_leaf, uint32_t mslot = 0, bool fill = false) {
+                                          uint32_t* out_len, uint32_t* out_leaf, uint32_t mslot = 0, bool fill = false,
+                                          bool* out_any_card = nullptr) {
     // ROOT: read the node from LDS mirror `mslot`; !ROOT && fill: read HBM and refresh that mirror
     const uint32_t mrow0 = mslot * k.rows;
     const int tid = threadIdx.x, l = tid & 15, g = tid >> 4;
@@ -412,6 +413,7 @@ __device__ __forceinline__ Cand node_best(const KC& k, int& cmp_par, uint32_t nd
     LA u32x4_t* vec = lds<u32x4_t>(k.L, vec_off);
     // running best of this lane's row group (identical in all 16 lanes of the group)
     uint32_t bi = MINMODE ? 0xFFFFu : 0u, bu = 1u, br = NONE;
+    bool anyc = false;  // some row (< len) of this lane's groups has a non-zero popcount
     if (k.RBc == 16) {
         const u32x4_t xv = vec[l];
         const uint32_t last = rows - 1;
@@ -470,6 +472,7 @@ __device__ __forceinline__ Cand node_best(const KC& k, int& cmp_par, uint32_t nd
                 const uint32_t both = row16_sum(popc4v(d[p] & xv) + (l == 0 ? cd[p] << 16 : 0u));
                 const uint32_t inter = both & 0xFFFFu;
                 uint32_t un = (both >> 16) + vec_pc - inter;
+                anyc = anyc || (r < len && (both >> 16) != 0);
                 if (want_counts && r < len && l == 0) { s_i[r] = inter; s_u[r] = un; }
                 un = un < 1u ? 1u : un;
                 const bool take = r < len && cand_better<MINMODE>(inter, un, r, bi, bu, br);
@@ -507,6 +510,7 @@ __device__ __forceinline__ Cand node_best(const KC& k, int& cmp_par, uint32_t nd
             const uint32_t both = row16_sum(part);
             const uint32_t inter = both & 0xFFFFu;
             uint32_t un = (both >> 16) + vec_pc - inter;
+            anyc = anyc || (r < len && (both >> 16) != 0);
             if (want_counts && r < len && l == 0) { s_i[r] = inter; s_u[r] = un; }
             un = un < 1u ? 1u : un;
             if (r < len && cand_better<MINMODE>(inter, un, r, bi, bu, br)) { bi = inter; bu = un; br = r; }
@@ -519,24 +523,34 @@ __device__ __forceinline__ Cand node_best(const KC& k, int& cmp_par, uint32_t nd
         const uint32_t ci = rdlane(bi, q), cu = rdlane(bu, q), cr = rdlane(br, q);
         if (cand_better<MINMODE>(ci, cu, cr, wi, wu, wr)) { wi = ci; wu = cu; wr = cr; }
     }
-    if ((tid & 63) == 0) wb[tid >> 6] = ((u64)wr << 32) | (wi << 16) | wu;
+    const uint32_t wany = __ballot(anyc) != 0ull ? 0x80000000u : 0u;  // rides in the row word's top bit
+    if ((tid & 63) == 0) wb[tid >> 6] = ((u64)(wr ^ wany) << 32) | (wi << 16) | wu;
     __syncthreads();
     Cand best;
+    uint32_t any_all = 0;
     {
         const u64 v0 = wb[0];
-        best.r = uni((uint32_t)(v0 >> 32));
+        const uint32_t hi = uni((uint32_t)(v0 >> 32));
+        // a wave without a valid row reports r = NONE (all ones): the flag bit is XORed in, so recover it
+        const uint32_t r0v = (hi | 0x80000000u) == NONE ? NONE : (hi & 0x7FFFFFFFu);
+        any_all |= r0v == NONE ? (~hi & 0x80000000u) : (hi & 0x80000000u);
+        best.r = r0v;
         best.i = uni((uint32_t)v0) >> 16;
         best.u = uni((uint32_t)v0) & 0xFFFFu;
     }
 #pragma unroll
     for (int w = 1; w < TW; ++w) {
         const u64 v = wb[w];
-        const uint32_t cr = uni((uint32_t)(v >> 32)), lo = uni((uint32_t)v);
+        const uint32_t hi = uni((uint32_t)(v >> 32));
+        const uint32_t cr = (hi | 0x80000000u) == NONE ? NONE : (hi & 0x7FFFFFFFu);
+        any_all |= cr == NONE ? (~hi & 0x80000000u) : (hi & 0x80000000u);
+        const uint32_t lo = uni((uint32_t)v);
         const uint32_t ci = lo >> 16, cu = lo & 0xFFFFu;
         if (cand_better<MINMODE>(ci, cu, cr, best.i, best.u, best.r)) { best.i = ci; best.u = cu; best.r = cr; }
     }
     if (out_len) *out_len = len;
     if (out_leaf) *out_leaf = leaf;
+    if (out_any_card) *out_any_card = any_all != 0;
     return best;
 }
 
@@ -905,8 +919,9 @@ __global__ __launch_bounds__(TB) void k_tree_insert(TreeDev* trees, const uint32
     // insertions mostly revisit them (the upper levels always, and BitBIRCH trees on diverse data
     // route whole runs of fingerprints down the same branch).  Tags are wave-uniform registers.
     uint32_t mir_node[MAXM], mir_len[MAXM], mir_leaf[MAXM];
+    bool mir_zero[MAXM];  // every centroid of the mirrored node is all-zero: similarity 0 to anything
 #pragma unroll
-    for (int q = 0; q < MAXM; ++q) { mir_node[q] = NONE; mir_len[q] = 0; mir_leaf[q] = 0; }
+    for (int q = 0; q < MAXM; ++q) { mir_node[q] = NONE; mir_len[q] = 0; mir_leaf[q] = 0; mir_zero[q] = false; }
     u64 ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     u64 tmark = PROF ? __builtin_amdgcn_s_memtime() : 0;
 #define PHASE(i) do { if constexpr (PROF) { const u64 _n = __builtin_amdgcn_s_memtime(); ph[i] += _n - tmark; tmark = _n; } } while (0)
@@ -1031,25 +1046,34 @@ __global__ __launch_bounds__(TB) void k_tree_insert(TreeDev* trees, const uint32
             bool bad = false;
             while (true) {
                 Cand best;
-                bool hit = false;
+                bool hit = false, zero = false, anyc = true;
 #pragma unroll
                 for (int q = 0; q < MAXM; ++q)
-                    if (q < nm && depth == q && mir_node[q] == nd) { hit = true; len = mir_len[q]; leaf = mir_leaf[q]; }
-                if (hit) {
+                    if (q < nm && depth == q && mir_node[q] == nd) { hit = true; len = mir_len[q]; leaf = mir_leaf[q]; zero = mir_zero[q]; }
+                if (hit && zero) {
+                    // every row of this node has an all-zero centroid: every similarity is 0, np.argmax
+                    // returns row 0 (bitbirch.py:320).  Only the ordering of HBM traffic remains to be done.
+                    __syncthreads();
+                    j = 0;
+                    link = uni(lds<uint32_t>(k.L, k.o.rc_link)[(uint32_t)depth * k.rows]);
+                } else if (hit) {
                     best = node_best<true, false>(k, cmp_par, nd, (int)len, k.o.x, el.pcx, false, false, false, nullptr, nullptr,
-                                                  (uint32_t)depth, false);
+                                                  (uint32_t)depth, false, &anyc);
                     j = best.r;
                     link = uni(lds<uint32_t>(k.L, k.o.rc_link)[(uint32_t)depth * k.rows + j]);
+#pragma unroll
+                    for (int q = 0; q < MAXM; ++q)
+                        if (depth == q) mir_zero[q] = !anyc;
                 } else {
                     const bool fill = depth < nm && k.RBc == 16;
                     best = node_best<false, false>(k, cmp_par, nd, -1, k.o.x, el.pcx, false, false, true, &len, &leaf,
-                                                   (uint32_t)depth, fill);
+                                                   (uint32_t)depth, fill, &anyc);
                     j = best.r;
                     link = uni(lds<uint32_t>(k.L, k.o.link)[cmp_par * k.rows + j]);
                     if (fill) {
 #pragma unroll
                         for (int q = 0; q < MAXM; ++q)
-                            if (depth == q) { mir_node[q] = nd; mir_len[q] = len; mir_leaf[q] = leaf; }
+                            if (depth == q) { mir_node[q] = nd; mir_len[q] = len; mir_leaf[q] = leaf; mir_zero[q] = !anyc; }
                     }
                 }
                 if (depth == 0) PHASE(6); else PHASE(7);
@@ -1201,6 +1225,11 @@ __global__ __launch_bounds__(TB) void k_tree_insert(TreeDev* trees, const uint32
                     }
                     stats[2]++;
                 }
+                if (leaf_mirrored && card != 0) {
+#pragma unroll
+                    for (int q = 0; q < MAXM; ++q)
+                        if (D == q) mir_zero[q] = false;
+                }
                 out_id = Tsub;
             } else {
                 // append_subcluster (bitbirch.py:284-287): new leaf BitFeature
@@ -1232,7 +1261,7 @@ __global__ __launch_bounds__(TB) void k_tree_insert(TreeDev* trees, const uint32
                     }
 #pragma unroll
                     for (int q = 0; q < MAXM; ++q)
-                        if (D == q) mir_len[q] = leaflen + 1;
+                        if (D == q) { mir_len[q] = leaflen + 1; mir_zero[q] = mir_zero[q] && el.pcx == 0; }
                 }
                 out_id = s;
                 overflow = leaflen + 1 > bf;
@@ -1258,6 +1287,7 @@ __global__ __launch_bounds__(TB) void k_tree_insert(TreeDev* trees, const uint32
                                 stg<uint32_t>(k.card + pm, pcs[1 + q]);
                                 if (q < MAXM && q < nm) lds<uint32_t>(k.L, k.o.rc_card)[(uint32_t)q * k.rows + jp] = pcs[1 + q];
                             }
+                            if (q < MAXM && pcs[1 + q] != 0) mir_zero[q] = false;
                         }
                     }
                 }
