@@ -46,6 +46,10 @@ constexpr int MAXD = 64;     // deepest tree handled
 constexpr int MAXFAST = 5;   // ancestor levels updated in the fused fast path
 constexpr int NRED = 2 + MAXFAST;
 constexpr int MAX_BF = 1023;
+constexpr int NPLW = 9;   // bit planes of a per-wave row count (<= 256 rows per wave at MAX_BF)
+constexpr int SPLIT_MLP = 16;  // uint8 member CF rows requested before the first is consumed (split)
+constexpr int SPLIT_MLP_WIDE = 4;  // same for rows of mixed width (32 B per thread and row)
+constexpr int NPLT = 11;  // bit planes of a whole-node row count (<= 1024)
 constexpr int MAXM = 4;  // levels of the current root-to-leaf path mirrored in LDS
 
 enum StopReason : int32_t {
@@ -97,6 +101,7 @@ struct TreeDev {
     uint32_t ctr[C_COUNT];
     unsigned long long stats[8];
     unsigned long long phase[8];  // shader-clock cycles per phase (thread 0), debug
+    unsigned long long sphase[8]; // same, inside split_node
     // job of the next launch
     const uint8_t* rows;
     long long row_stride;
@@ -125,6 +130,7 @@ struct Smem {
     uint32_t ctr;                 // C_COUNT u32
     uint32_t stats;               // 8 u64
     uint32_t bc;                  // 16 u32 broadcast scratch
+    uint32_t planes;              // TW x NPLW x 64 u32 bit-sliced column counters (split)
     uint32_t rc_cent, rc_card, rc_link;  // LDS mirrors of the nodes on the current path (MAXM levels)
     uint32_t total;
 };
@@ -148,6 +154,7 @@ __host__ __device__ inline Smem smem_layout(int bf, int RB, int nm) {
     s.path_node = take(MAXD * 4); s.path_row = take(MAXD * 4); s.path_len = take(MAXD * 4);
     s.path_slot = take(MAXD * 4); s.path_n = take(MAXD * 4);
     s.ctr = take(C_COUNT * 4); s.stats = take(8 * 8); s.bc = take(16 * 4);
+    s.planes = take((size_t)TW * NPLW * 64 * 4);
     if (nm > 0) {
         s.rc_cent = take((size_t)nm * m * ((size_t)RB + 16));
         s.rc_card = take((size_t)nm * m * 4);
@@ -289,6 +296,35 @@ __device__ __forceinline__ void cf_load8(const KC& k, uint32_t slotw, int b, uin
     } else {
         const u32x4_t q0 = ldg<u32x4_t>(k.cf32 + idx), q1 = ldg<u32x4_t>(k.cf32 + idx + 4);
         v[0] = q0.x; v[1] = q0.y; v[2] = q0.z; v[3] = q0.w;
+        v[4] = q1.x; v[5] = q1.y; v[6] = q1.z; v[7] = q1.w;
+    }
+}
+
+// The same load split in two so that several rows can be in flight before the first unpack.
+// The request itself is branch-free (a load inside a tier branch makes the compiler wait for it at
+// the branch's join): always two 16-byte loads, the second one only meaningful for cf32 and
+// pointed at the same line otherwise.  cf8 rows are 8-byte aligned and over-read by 8 bytes
+// (the pools carry 64 bytes of slack; amdhsa runs with unaligned access enabled).
+__device__ __forceinline__ void cf_load_raw(const KC& k, uint32_t slotw, int b, u32x4_t (&raw)[2]) {
+    const uint32_t tier = slotw >> 30;
+    // mask arithmetic, not ?: - the compiler turns a three-way pointer select into a table in scratch
+    const u64 m0 = 0ull - (u64)(tier == 0), m1 = 0ull - (u64)(tier == 1), m2 = 0ull - (u64)(tier >= 2);
+    const uint8_t* base = (const uint8_t*)(((u64)(uintptr_t)k.cf8 & m0) | ((u64)(uintptr_t)k.cf16 & m1) | ((u64)(uintptr_t)k.cf32 & m2));
+    const size_t off = ((size_t)(slotw & 0x3FFFFFFFu) * (size_t)k.F + (size_t)b * 8) << tier;
+    raw[0] = ldg<u32x4_t>(base + off);
+    raw[1] = ldg<u32x4_t>(base + off + (tier == 2 ? 16 : 0));
+}
+__device__ __forceinline__ void cf_unpack_raw(uint32_t tier, const u32x4_t (&raw)[2], uint32_t v[8]) {
+    const u32x4_t q = raw[0];
+    if (tier == 0) {
+        v[0] = q.x & 0xFF; v[1] = (q.x >> 8) & 0xFF; v[2] = (q.x >> 16) & 0xFF; v[3] = q.x >> 24;
+        v[4] = q.y & 0xFF; v[5] = (q.y >> 8) & 0xFF; v[6] = (q.y >> 16) & 0xFF; v[7] = q.y >> 24;
+    } else if (tier == 1) {
+        v[0] = q.x & 0xFFFF; v[1] = q.x >> 16; v[2] = q.y & 0xFFFF; v[3] = q.y >> 16;
+        v[4] = q.z & 0xFFFF; v[5] = q.z >> 16; v[6] = q.w & 0xFFFF; v[7] = q.w >> 16;
+    } else {
+        const u32x4_t q1 = raw[1];
+        v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
         v[4] = q1.x; v[5] = q1.y; v[6] = q1.z; v[7] = q1.w;
     }
 }
@@ -668,18 +704,100 @@ __device__ __forceinline__ uint32_t alloc_n(const KC& k, uint32_t& reg, uint32_t
     }
 }
 
+// Majority vote over the m centroid rows of a node -> packed vector in LDS (o.vec), the
+// centroid of the node's centroids (bitbirch.py:162-211 via centroid_from_sum, _py_similarity.py:
+// 12-42: bit = 2*count >= m).  Column counts are kept bit-sliced: every lane owns one dword (32
+// columns) of the row, every wave a quarter of the rows; adding a row is a ripple of half adders
+// over the count's NPW bit planes.  The four partial counts meet in LDS, are added with full
+// adders (NPT planes) and compared with ceil(m/2) plane by plane, which leaves the packed
+// majority dword directly.  Needs m <= 4 * (2^NPW - 1) and m < 2^NPT.
+template <int NPW, int NPT>
+__device__ __forceinline__ void majority_rows(const KC& k, bool lm, uint32_t mrow0, const uint8_t* cent, uint32_t m) {
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int RBdw = k.RB / 4;
+    const uint32_t half = (m + 1) >> 1;
+    LA uint32_t* planes = lds<uint32_t>(k.L, k.o.planes);
+    for (int d0 = 0; d0 < RBdw; d0 += 64) {
+        const int d = d0 + lane;
+        const bool actd = d < RBdw;
+        const int dc = actd ? d : 0;
+        uint32_t p[NPW];
+#pragma unroll
+        for (int i = 0; i < NPW; ++i) p[i] = 0;
+        for (uint32_t r0 = (uint32_t)wave; r0 < m; r0 += 4 * TW) {
+            uint32_t c[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {  // four rows requested before the first is consumed
+                const uint32_t r = r0 + u * TW;
+                const uint32_t rc = r < m ? r : m - 1;
+                if (lm) c[u] = *(LA uint32_t*)(k.L + k.o.rc_cent + (mrow0 + rc) * k.RBS + (uint32_t)dc * 4);
+                else c[u] = ldg<uint32_t>(cent + (size_t)rc * k.RB + (size_t)dc * 4);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                uint32_t cc = (actd && r0 + u * TW < m) ? c[u] : 0u;
+#pragma unroll
+                for (int i = 0; i < NPW; ++i) {
+                    const uint32_t t = p[i] & cc;
+                    p[i] ^= cc;
+                    cc = t;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NPW; ++i) planes[(wave * NPLW + i) * 64 + lane] = p[i];
+        __syncthreads();
+        if (wave == 0) {
+            uint32_t sacc[NPT];
+#pragma unroll
+            for (int i = 0; i < NPT; ++i) sacc[i] = (i < NPW) ? p[i] : 0u;
+#pragma unroll
+            for (int w = 1; w < TW; ++w) {
+                uint32_t carry = 0;
+#pragma unroll
+                for (int i = 0; i < NPT; ++i) {
+                    const uint32_t a = sacc[i], bq = (i < NPW) ? planes[(w * NPLW + i) * 64 + lane] : 0u;
+                    const uint32_t x = a ^ bq;
+                    sacc[i] = x ^ carry;
+                    carry = (a & bq) | (carry & x);
+                }
+            }
+            uint32_t gt = 0, eq = 0xFFFFFFFFu;
+#pragma unroll
+            for (int i = NPT - 1; i >= 0; --i) {
+                const uint32_t tb = ((half >> i) & 1u) ? 0xFFFFFFFFu : 0u;
+                gt |= eq & sacc[i] & ~tb;
+                eq &= ~(sacc[i] ^ tb);
+            }
+            if (actd) lds<uint32_t>(k.L, k.o.vec)[d] = gt | eq;
+        }
+        __syncthreads();
+    }
+}
+
 // ---- _split_node (bitbirch.py:162-211) -------------------------------------------------
 // Splits node `nd` (len = bf+1 rows).  Leaves the two tracking BitFeatures' centroids in
 // LDS (o.cA / o.cB) and publishes through bc: [0]=node1 [3]=cardA [4]=cardB [7]=nA [8]=nB
 // [9]=slotA [10]=slotB [11]=n overflow flag.
-template <bool SUB>
-__device__ __forceinline__ void split_node(const KC& k, int& red_slot, int& cmp_par, uint32_t nd, uint32_t& cN,
-                                           uint32_t& c32, uint32_t& cFirst, uint32_t* gctr) {
+template <bool SUB, bool PROF>
+__device__ __forceinline__ void split_node(const KC& k, const Elem& el, int& red_slot, int& cmp_par, uint32_t nd, uint32_t ms,
+                                           bool ms_valid, uint32_t trk_slot, uint32_t& cN, uint32_t& c32, uint32_t& cFirst,
+                                           uint32_t* gctr, u64 (&sph)[8]) {
+    // ms: LDS mirror slot to work in (2048-bit rows only); ms_valid: it already holds nd's rows.
+    // trk_slot: CF slot word of the tracking BitFeature that describes nd in its parent (NONE for
+    // the root).  It has not received the element being inserted yet, so the CFs of nd's rows add
+    // up to exactly CF(trk_slot) + element: only the smaller half is summed, the other half is the
+    // difference.
     const int tid = threadIdx.x;
+    u64 smark = PROF ? __builtin_amdgcn_s_memtime() : 0;
+#define SPH(i) do { if constexpr (PROF) { const u64 _n = __builtin_amdgcn_s_memtime(); sph[i] += _n - smark; smark = _n; } } while (0)
     const uint32_t rows = k.rows;
     const size_t meta = (size_t)nd * rows;
-    const uint32_t m = uni(ldg<uint32_t>(k.hdr + nd));  // NodeHdr.len
+    const u32x4_t hold = ldg<u32x4_t>(k.hdr + nd);  // {len, leaf, prev, next}
+    const uint32_t m = uni(hold.x);
     const int nb = k.nb;
+    const bool lm = k.nm > 0;  // rows are staged in (or already live in) LDS mirror `ms`
+    const uint32_t mrow0 = ms * rows;
     uint8_t* cent = k.cent + meta * (size_t)k.RB;
     LA uint32_t* bc = lds<uint32_t>(k.L, k.o.bc);
     LA uint32_t* dst = lds<uint32_t>(k.L, k.o.dst);
@@ -687,37 +805,61 @@ __device__ __forceinline__ void split_node(const KC& k, int& red_slot, int& cmp_
     LA uint32_t* mlink = lds<uint32_t>(k.L, k.o.mlink);
     LA u32x4_t* mrm = lds<u32x4_t>(k.L, k.o.mrm);
     LA u32x4_t* vec = lds<u32x4_t>(k.L, k.o.vec);
-    // 0. row metadata to LDS; zero the comparison vector padding
+    LA uint32_t* lst = lds<uint32_t>(k.L, k.o.i1);  // CF slots of the smaller half (after step 5)
+    // 0. row metadata (and, if needed, the centroid rows) to LDS; zero the comparison vector padding
     for (uint32_t r = tid; r < m; r += TB) {
-        mcard[r] = ldg<uint32_t>(k.card + meta + r);
+        const uint32_t cd = ldg<uint32_t>(k.card + meta + r);
+        mcard[r] = cd;
+        if (lm && !ms_valid) lds<uint32_t>(k.L, k.o.rc_card)[mrow0 + r] = cd;
         mlink[r] = ldg<uint32_t>(k.link + meta + r);
         mrm[2 * r] = ldg<u32x4_t>((uint8_t*)(k.rm + meta + r));
         mrm[2 * r + 1] = ldg<u32x4_t>((uint8_t*)(k.rm + meta + r) + 16);
     }
+    if (lm && !ms_valid) {
+        const uint32_t total = m * 16u;
+        for (uint32_t i0 = 0; i0 < total; i0 += 4 * TB) {  // four 16-byte pieces per thread in flight
+            u32x4_t t4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t i = i0 + u * TB + tid;
+                t4[u] = ldg<u32x4_t>(cent + (size_t)(i < total ? i : total - 1) * 16);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t i = i0 + u * TB + tid;
+                if (i < total) *(LA u32x4_t*)(k.L + k.o.rc_cent + (mrow0 + (i >> 4)) * k.RBS + (i & 15u) * 16) = t4[u];
+            }
+        }
+    }
     for (int ch = tid; ch < k.RBc; ch += TB) vec[ch] = (u32x4_t)(0);
     __syncthreads();
-    // 1. majority centroid of the node's centroids (column sums of the unpacked rows)
-    for (int b = tid; b < nb; b += TB) {
-        uint32_t acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (uint32_t r = 0; r < m; ++r) {
-            const uint32_t v = ldg<uint8_t>(cent + (size_t)r * k.RB + b);
-#pragma unroll
-            for (int q = 0; q < 8; ++q) acc[q] += (v >> (7 - q)) & 1u;
-        }
-        lds<uint8_t>(k.L, k.o.vec)[b] = (uint8_t)centroid_byte(acc, m);
-    }
-    __syncthreads();
+    SPH(0);
+    // 1. majority centroid of the node's centroids (bit-sliced column counts)
+    if (m <= 124) majority_rows<5, 7>(k, lm, mrow0, cent, m);
+    else majority_rows<NPLW, NPLT>(k, lm, mrow0, cent, m);
     const uint32_t pc = lds_vec_popcount(k, k.o.vec);
-    // 2. fp1 = first argmin of similarity to that centroid
-    const uint32_t f1 = node_best<false, true>(k, cmp_par, nd, (int)m, k.o.vec, pc, false, false, false, nullptr, nullptr).r;
-    // 3. similarities to fp1; fp2 = first argmin
-    for (int ch = tid; ch < k.RBc; ch += TB) vec[ch] = ldg<u32x4_t>(cent + (size_t)f1 * k.RB + (size_t)ch * 16);
-    __syncthreads();
-    const uint32_t f2 = node_best<false, true>(k, cmp_par, nd, (int)m, k.o.vec, uni(mcard[f1]), true, false, false, nullptr, nullptr).r;
-    // 4. similarities to fp2
-    for (int ch = tid; ch < k.RBc; ch += TB) vec[ch] = ldg<u32x4_t>(cent + (size_t)f2 * k.RB + (size_t)ch * 16);
-    __syncthreads();
-    (void)node_best<false, true>(k, cmp_par, nd, (int)m, k.o.vec, uni(mcard[f2]), true, true, false, nullptr, nullptr);
+    SPH(1);
+    // 2. fp1 = first argmin of similarity to that centroid; 3. similarities to fp1, fp2 = first
+    //    argmin; 4. similarities to fp2
+    uint32_t f1;
+    if (lm) {
+        f1 = node_best<true, true>(k, cmp_par, nd, (int)m, k.o.vec, pc, false, false, false, nullptr, nullptr, ms).r;
+        for (int ch = tid; ch < k.RBc; ch += TB) vec[ch] = *(LA u32x4_t*)(k.L + k.o.rc_cent + (mrow0 + f1) * k.RBS + ch * 16);
+        __syncthreads();
+        const uint32_t f2 = node_best<true, true>(k, cmp_par, nd, (int)m, k.o.vec, uni(mcard[f1]), true, false, false, nullptr, nullptr, ms).r;
+        for (int ch = tid; ch < k.RBc; ch += TB) vec[ch] = *(LA u32x4_t*)(k.L + k.o.rc_cent + (mrow0 + f2) * k.RBS + ch * 16);
+        __syncthreads();
+        (void)node_best<true, true>(k, cmp_par, nd, (int)m, k.o.vec, uni(mcard[f2]), true, true, false, nullptr, nullptr, ms);
+    } else {
+        f1 = node_best<false, true>(k, cmp_par, nd, (int)m, k.o.vec, pc, false, false, false, nullptr, nullptr).r;
+        for (int ch = tid; ch < k.RBc; ch += TB) vec[ch] = ldg<u32x4_t>(cent + (size_t)f1 * k.RB + (size_t)ch * 16);
+        __syncthreads();
+        const uint32_t f2 = node_best<false, true>(k, cmp_par, nd, (int)m, k.o.vec, uni(mcard[f1]), true, false, false, nullptr, nullptr).r;
+        for (int ch = tid; ch < k.RBc; ch += TB) vec[ch] = ldg<u32x4_t>(cent + (size_t)f2 * k.RB + (size_t)ch * 16);
+        __syncthreads();
+        (void)node_best<false, true>(k, cmp_par, nd, (int)m, k.o.vec, uni(mcard[f2]), true, true, false, nullptr, nullptr);
+    }
+    SPH(2);
     // 5. node1_closer = sims_fp1 > sims_fp2 (exact cross-multiplication), node1_closer[fp1] = True
     {
         LA uint32_t* i1 = lds<uint32_t>(k.L, k.o.i1);
@@ -732,42 +874,62 @@ __device__ __forceinline__ void split_node(const KC& k, int& red_slot, int& cmp_
         }
     }
     __syncthreads();
-    if (tid == 0) {
+    if (tid < 64) {
+        // stable partition positions: ballot prefix counts, 64 rows at a time
         uint32_t n1 = 0, n2 = 0;
         u64 nA = 0, nB = 0;
-        for (uint32_t r = 0; r < m; ++r) {
-            const uint32_t nr = mrm[2 * r].y;  // RowMeta.n
-            if (dst[r] & 0x80000000u) {
-                dst[r] = 0x80000000u | n1++;
-                nA += nr;
-            } else {
-                dst[r] = n2++;
-                nB += nr;
+        const u64 below = (1ull << tid) - 1ull;
+        for (uint32_t r0 = 0; r0 < m; r0 += 64) {
+            const uint32_t r = r0 + tid;
+            const bool valid = r < m;
+            const bool to1 = valid && (dst[r] & 0x80000000u) != 0;
+            const u64 nr = valid ? (u64)mrm[2 * r].y : 0ull;  // RowMeta.n
+            const u64 m1 = __ballot(to1), mv = __ballot(valid);
+            const u64 m2 = mv & ~m1;
+            if (valid) dst[r] = to1 ? (0x80000000u | (n1 + (uint32_t)__popcll(m1 & below))) : (n2 + (uint32_t)__popcll(m2 & below));
+            nA += wsum64(to1 ? nr : 0ull);
+            nB += wsum64(valid && !to1 ? nr : 0ull);
+            n1 += (uint32_t)__popcll(m1);
+            n2 += (uint32_t)__popcll(m2);
+        }
+        // CF slots of the smaller half, in row order
+        const bool small1 = n1 <= n2;
+        for (uint32_t r0 = 0; r0 < m; r0 += 64) {
+            const uint32_t r = r0 + tid;
+            if (r < m) {
+                const uint32_t d = dst[r];
+                if (((d & 0x80000000u) != 0) == small1) lst[d & 0x7FFFFFFFu] = mrm[2 * r].z;  // RowMeta.slot
             }
         }
-        bc[7] = (uint32_t)nA;
-        bc[8] = (uint32_t)nB;
-        bc[11] = (nA > 0xFFFFFFFFull || nB > 0xFFFFFFFFull) ? 1u : 0u;
-        bc[5] = n1;
-        bc[6] = n2;
-        lds<u64>(k.L, k.o.stats)[4]++;
-        lds<u64>(k.L, k.o.stats)[5]++;
+        if (tid == 0) {
+            bc[7] = (uint32_t)nA;
+            bc[8] = (uint32_t)nB;
+            bc[11] = (nA > 0xFFFFFFFFull || nB > 0xFFFFFFFFull) ? 1u : 0u;
+            bc[5] = n1;
+            bc[6] = n2;
+            lds<u64>(k.L, k.o.stats)[4]++;
+            lds<u64>(k.L, k.o.stats)[5]++;
+        }
     }
     // 6. ids for the new node and the two tracking BitFeatures (always cf32): every thread
     //    keeps the (uniform) allocation counters in registers
     const uint32_t node1 = alloc_n<SUB>(k, cN, gctr + C_NODES, 1, 14);
     const uint32_t slotA_i = alloc_n<SUB>(k, c32, gctr + C_N32, 2, 15), slotB_i = slotA_i + 1;
-    const u32x4_t hold = ldg<u32x4_t>(k.hdr + nd);  // {len, leaf, prev, next}
     const uint32_t was_leaf = uni(hold.y), prev_leaf = uni(hold.z);
     if (was_leaf && prev_leaf == NONE) {
         if constexpr (SUB) { if (tid == 0) stg<uint32_t>(gctr + C_FIRST_LEAF, node1); }
         else cFirst = node1;
     }
-    // 7a. stage all centroid rows (kept rows are compacted in place afterwards)
-    for (uint32_t i = tid; i < m * (uint32_t)k.RBc; i += TB)
-        stg<u32x4_t>(k.scratch + (size_t)i * 16, ldg<u32x4_t>(cent + (size_t)i * 16));
+    SPH(3);
+    // 7a. stage all centroid rows (kept rows are compacted in place afterwards); rows that
+    //     already sit in LDS need no staging
+    if (!lm) {
+        for (uint32_t i = tid; i < m * (uint32_t)k.RBc; i += TB)
+            stg<u32x4_t>(k.scratch + (size_t)i * 16, ldg<u32x4_t>(cent + (size_t)i * 16));
+    }
     __syncthreads();
     const u64 nA = uni(bc[7]), nB = uni(bc[8]);
+    const uint32_t n1 = uni(bc[5]), n2 = uni(bc[6]);
     const uint32_t slotA = (2u << 30) | slotA_i, slotB = (2u << 30) | slotB_i;
     if (tid == 0) {
         // 9. leaf chain: node1 goes immediately before nd (bitbirch.py:182-188)
@@ -779,14 +941,14 @@ __device__ __forceinline__ void split_node(const KC& k, int& red_slot, int& cmp_
         // concurrent gates never race on the leaf chain
         const u32x4_t h = hold;
         u32x4_t h1;
-        h1.x = bc[5]; h1.y = h.y; h1.z = NONE; h1.w = NONE;
+        h1.x = n1; h1.y = h.y; h1.z = NONE; h1.w = NONE;
         if (h.y) {
             h1.z = h.z;
             if (h.z != NONE) stg<uint32_t>((uint8_t*)(k.hdr + h.z) + 12, node1);
             h1.w = nd;
         }
         stg<u32x4_t>(k.hdr + node1, h1);
-        stg<uint32_t>((uint8_t*)(k.hdr + nd), bc[6]);
+        stg<uint32_t>((uint8_t*)(k.hdr + nd), n2);
         if (h.y) stg<uint32_t>((uint8_t*)(k.hdr + nd) + 8, node1);
     }
     // 7b. distribute rows in their original order
@@ -796,7 +958,10 @@ __device__ __forceinline__ void split_node(const KC& k, int& red_slot, int& cmp_
             const uint32_t r = i / k.RBc, ch = i % k.RBc;
             const uint32_t d = dst[r];
             uint8_t* dstbase = (d & 0x80000000u) ? cent1 : cent;
-            stg<u32x4_t>(dstbase + (size_t)(d & 0x7FFFFFFFu) * k.RB + (size_t)ch * 16, ldg<u32x4_t>(k.scratch + (size_t)i * 16));
+            u32x4_t v;
+            if (lm) v = *(LA u32x4_t*)(k.L + k.o.rc_cent + (mrow0 + r) * k.RBS + ch * 16);
+            else v = ldg<u32x4_t>(k.scratch + (size_t)i * 16);
+            stg<u32x4_t>(dstbase + (size_t)(d & 0x7FFFFFFFu) * k.RB + (size_t)ch * 16, v);
         }
         for (uint32_t r = tid; r < m; r += TB) {
             const uint32_t d = dst[r];
@@ -807,6 +972,7 @@ __device__ __forceinline__ void split_node(const KC& k, int& red_slot, int& cmp_
             stg<u32x4_t>((uint8_t*)(k.rm + mm) + 16, mrm[2 * r + 1]);
         }
     }
+    SPH(4);
     // 8. tracking BitFeatures: CF = sum of member CFs; centroid from the final CF
     for (int ch = tid; ch < k.RBc; ch += TB) {
         lds<u32x4_t>(k.L, k.o.cA)[ch] = (u32x4_t)(0);
@@ -814,19 +980,91 @@ __device__ __forceinline__ void split_node(const KC& k, int& red_slot, int& cmp_
     }
     __syncthreads();
     u64 cards[2] = {0, 0};
+    const bool by_difference = trk_slot != NONE;
+    const bool small1 = n1 <= n2;
+    const uint32_t ns = small1 ? n1 : n2;
     for (int b = tid; b < nb; b += TB) {
         uint32_t accA[8] = {0, 0, 0, 0, 0, 0, 0, 0}, accB[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (uint32_t r = 0; r < m; ++r) {
-            uint32_t v[8];
-            cf_load8(k, uni(mrm[2 * r].z), b, v);  // RowMeta.slot
-            if (uni(dst[r]) & 0x80000000u) {
+        SPH(5);
+        if (by_difference) {
+            // the element and the old tracking CF first: they are needed last
+            uint32_t tot[8], x8[8], sm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            cf32_load8(k, trk_slot, b, tot);
+            elem_cols(k, el, b, x8);
+            for (uint32_t r0 = 0; r0 < ns; r0 += SPLIT_MLP) {  // this many member CFs in flight
+                uint32_t sw[SPLIT_MLP], tiers = 0;
 #pragma unroll
-                for (int q = 0; q < 8; ++q) accA[q] += v[q];
-            } else {
+                for (int u = 0; u < SPLIT_MLP; ++u) {
+                    sw[u] = uni(lst[r0 + u < ns ? r0 + u : ns - 1]);
+                    tiers |= sw[u];
+                }
+                if ((tiers >> 30) == 0) {
+                    // uint8 CFs only (the usual leaf): 8 bytes per row and thread, summed as four
+                    // pairs of 16-bit lanes (16 rows x 255 cannot overflow them)
+                    u32x2_t q[SPLIT_MLP];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) accB[q] += v[q];
+                    for (int u = 0; u < SPLIT_MLP; ++u)
+                        q[u] = ldg<u32x2_t>(k.cf8 + (size_t)sw[u] * (size_t)k.F + (size_t)b * 8);
+                    uint32_t lx = 0, hx = 0, ly = 0, hy = 0;
+#pragma unroll
+                    for (int u = 0; u < SPLIT_MLP; ++u) {
+                        if (r0 + u < ns) {
+                            lx += q[u].x & 0x00FF00FFu; hx += (q[u].x >> 8) & 0x00FF00FFu;
+                            ly += q[u].y & 0x00FF00FFu; hy += (q[u].y >> 8) & 0x00FF00FFu;
+                        }
+                    }
+                    sm[0] += lx & 0xFFFFu; sm[1] += hx & 0xFFFFu; sm[2] += lx >> 16; sm[3] += hx >> 16;
+                    sm[4] += ly & 0xFFFFu; sm[5] += hy & 0xFFFFu; sm[6] += ly >> 16; sm[7] += hy >> 16;
+                } else {
+#pragma unroll
+                    for (int u0 = 0; u0 < SPLIT_MLP; u0 += SPLIT_MLP_WIDE) {
+                        u32x4_t raw[SPLIT_MLP_WIDE][2];
+#pragma unroll
+                        for (int u = 0; u < SPLIT_MLP_WIDE; ++u) cf_load_raw(k, sw[u0 + u], b, raw[u]);
+#pragma unroll
+                        for (int u = 0; u < SPLIT_MLP_WIDE; ++u) {
+                            if (r0 + u0 + u < ns) {
+                                uint32_t v[8];
+                                cf_unpack_raw(sw[u0 + u] >> 30, raw[u], v);
+#pragma unroll
+                                for (int q8 = 0; q8 < 8; ++q8) sm[q8] += v[q8];
+                            }
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int q8 = 0; q8 < 8; ++q8) {
+                const uint32_t other = tot[q8] + x8[q8] - sm[q8];
+                accA[q8] = small1 ? sm[q8] : other;
+                accB[q8] = small1 ? other : sm[q8];
+            }
+        } else {
+            for (uint32_t r0 = 0; r0 < m; r0 += SPLIT_MLP_WIDE) {
+                u32x4_t raw[SPLIT_MLP_WIDE][2];
+                uint32_t sw[SPLIT_MLP_WIDE];
+#pragma unroll
+                for (int u = 0; u < SPLIT_MLP_WIDE; ++u) {
+                    sw[u] = uni(mrm[2 * (r0 + u < m ? r0 + u : m - 1)].z);  // RowMeta.slot
+                    cf_load_raw(k, sw[u], b, raw[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < SPLIT_MLP_WIDE; ++u) {
+                    if (r0 + u < m) {
+                        uint32_t v[8];
+                        cf_unpack_raw(sw[u] >> 30, raw[u], v);
+                        if (uni(dst[r0 + u]) & 0x80000000u) {
+#pragma unroll
+                            for (int q8 = 0; q8 < 8; ++q8) accA[q8] += v[q8];
+                        } else {
+#pragma unroll
+                            for (int q8 = 0; q8 < 8; ++q8) accB[q8] += v[q8];
+                        }
+                    }
+                }
             }
         }
+        SPH(6);
         cf_store8(k, slotA, b, accA);
         cf_store8(k, slotB, b, accB);
         const uint32_t ba = centroid_byte(accA, nA), bb_ = centroid_byte(accB, nB);
@@ -841,6 +1079,8 @@ __device__ __forceinline__ void split_node(const KC& k, int& red_slot, int& cmp_
         bc[4] = (uint32_t)cards[1];
     }
     __syncthreads();
+    SPH(7);
+#undef SPH
 }
 
 // CF += element on one ancestor row (closest_subcluster.update, bitbirch.py:352-357); slow path
@@ -923,6 +1163,7 @@ __global__ __launch_bounds__(TB) void k_tree_insert(TreeDev* trees, const uint32
 #pragma unroll
     for (int q = 0; q < MAXM; ++q) { mir_node[q] = NONE; mir_len[q] = 0; mir_leaf[q] = 0; mir_zero[q] = false; }
     u64 ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    u64 sph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     u64 tmark = PROF ? __builtin_amdgcn_s_memtime() : 0;
 #define PHASE(i) do { if constexpr (PROF) { const u64 _n = __builtin_amdgcn_s_memtime(); ph[i] += _n - tmark; tmark = _n; } } while (0)
 
@@ -1133,10 +1374,12 @@ __global__ __launch_bounds__(TB) void k_tree_insert(TreeDev* trees, const uint32
             if (fast) {
                 if (act) {
                     elem_cols(k, el, b0, xs);
-                    cf_load8(k, slotT, b0, vL);
+                    u32x4_t rawL[2];
+                    cf_load_raw(k, slotT, b0, rawL);  // leaf and ancestor CFs travel together
 #pragma unroll
                     for (int q = 0; q < MAXFAST; ++q)
                         if (q < DT) cf32_load8(k, tslot[q], b0, vT[q]);
+                    cf_unpack_raw(slotT >> 30, rawL, vL);
                     if (wide_dot) {
 #pragma unroll
                         for (int q = 0; q < 8; ++q) dot += (u64)vL[q] * xs[q];
@@ -1308,7 +1551,18 @@ __global__ __launch_bounds__(TB) void k_tree_insert(TreeDev* trees, const uint32
             bool range_bad = false;
             while (true) {
                 const uint32_t nd = uni(path_node[lvl]);
-                split_node<SUB>(k, red_slot, cmp_par, nd, cN, c32, cFirst, gctr);
+                uint32_t ms = 0;
+                bool ms_valid = false;
+                if (nm > 0) {
+                    ms = lvl < nm ? (uint32_t)lvl : (uint32_t)(nm - 1);
+#pragma unroll
+                    for (int q = 0; q < MAXM; ++q)
+                        if (q == lvl && lvl == D && q < nm && mir_node[q] == nd) ms_valid = true;  // leaf mirror, appended row included
+                }
+                const uint32_t trk = lvl > 0 ? uni(path_slot[lvl - 1]) : NONE;
+                split_node<SUB, PROF>(k, el, red_slot, cmp_par, nd, ms, ms_valid, trk, cN, c32, cFirst, gctr, sph);
+#pragma unroll
+                for (int q = 0; q < MAXM; ++q) mir_node[q] = NONE;  // slot `ms` was used as workspace
                 const uint32_t node1 = uni(bc[0]), cardA = uni(bc[3]), cardB = uni(bc[4]);
                 const uint32_t nA = uni(bc[7]), nB = uni(bc[8]);
                 const uint32_t slotA = (2u << 30) | uni(bc[9]), slotB = (2u << 30) | uni(bc[10]);
@@ -1372,7 +1626,7 @@ __global__ __launch_bounds__(TB) void k_tree_insert(TreeDev* trees, const uint32
         if (tid == 0) {
             T->processed = e;
             T->stop_reason = stop;
-            if constexpr (PROF) for (int i = 0; i < 8; ++i) T->phase[i] += ph[i];
+            if constexpr (PROF) for (int i = 0; i < 8; ++i) { T->phase[i] += ph[i]; T->sphase[i] += sph[i]; }
         }
     }
 #undef PHASE
@@ -1576,7 +1830,7 @@ namespace {
 template <typename T>
 int grow_pool(T*& p, size_t old_elems, size_t new_elems) {
     T* np_ = nullptr;
-    BB_HIP(hipMalloc(&np_, new_elems * sizeof(T)));
+    BB_HIP(hipMalloc(&np_, new_elems * sizeof(T) + 64));  // slack: cf_load_raw over-reads 8 bytes
     if (p && old_elems) BB_HIP(hipMemcpy(np_, p, old_elems * sizeof(T), hipMemcpyDeviceToDevice));
     if (p) BB_HIP(hipFree(p));
     p = np_;
@@ -1640,6 +1894,7 @@ int init_empty(bbh_tree* t) {
     h.ctr[C_DEPTH] = 1;
     std::memset(h.stats, 0, sizeof(h.stats));
     std::memset(h.phase, 0, sizeof(h.phase));
+    std::memset(h.sphase, 0, sizeof(h.sphase));
     h.stats[5] = 1;
     t->chain_valid = false;
     return BBH_OK;
@@ -1756,6 +2011,7 @@ int run_insert_multi(std::vector<Job>& jobs, hipStream_t s) {
             std::memcpy(h.ctr, back.ctr, sizeof(h.ctr));
             std::memcpy(h.stats, back.stats, sizeof(h.stats));
             std::memcpy(h.phase, back.phase, sizeof(h.phase));
+            std::memcpy(h.sphase, back.sphase, sizeof(h.sphase));
             j.done += back.processed;
             j.stalls = back.processed == 0 ? j.stalls + 1 : 0;
             if (j.stalls > 3) { rc = bb::fail(BBH_ERR_CAPACITY, "tree engine made no progress (stop reason %d)", back.stop_reason); break; }
@@ -2089,6 +2345,9 @@ extern "C" int bbh_tree_stats(bbh_tree* t, uint64_t* out8) {
         fprintf(stderr, "[bbhip phases, cycles/insert]");
         const double n = (double)(t->h.stats[2] + t->h.stats[3]);
         for (int i = 0; i < 8; ++i) fprintf(stderr, " p%d=%.0f", i, n > 0 ? (double)t->h.phase[i] / n : 0.0);
+        fprintf(stderr, "\n[bbhip split phases, cycles/split]");
+        const double ns = (double)t->h.stats[4];
+        for (int i = 0; i < 8; ++i) fprintf(stderr, " s%d=%.0f", i, ns > 0 ? (double)t->h.sphase[i] / ns : 0.0);
         fprintf(stderr, "\n");
     }
     return BBH_OK;
