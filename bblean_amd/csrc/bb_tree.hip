@@ -34,6 +34,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <future>
 
 using namespace bbd;
 
@@ -2158,6 +2159,73 @@ extern "C" int bbh_tree_reset(bbh_tree* t) {
     return init_empty(t);  // pools are kept and reused
 }
 
+// ---------------------------------------------------------------------------------------
+// Streaming ingest of host-resident rows (fingerprint files are memory-mapped by the caller;
+// the reference walks them with mmap + madvise, _memory.py:74-126).  Two slabs in HBM and two
+// pinned bounce buffers: while the tree kernel consumes slab i, a helper thread pages slab i+1
+// in from the (pageable, possibly file-backed) source, and a dedicated copy stream moves it
+// over PCIe.  The clustering kernel never waits for the host after the first slab, and the
+// device footprint of the input is 2 slabs regardless of the file size.
+// ---------------------------------------------------------------------------------------
+struct HostSlabs {
+    static constexpr size_t kSlabBytes = 64ull << 20;
+    int device = 0;
+    const uint8_t* src = nullptr;
+    size_t unit = 0;           // bytes per row (stride)
+    int64_t total = 0, per = 0;  // rows in all / per slab
+    uint8_t* pin[2] = {nullptr, nullptr};
+    uint8_t* dev[2] = {nullptr, nullptr};
+    hipStream_t cs = nullptr;
+    std::future<int> pending;
+    int64_t next = 0;  // first row of the slab being fetched
+
+    int init(int device_, const void* src_, size_t unit_, int64_t total_) {
+        device = device_; src = (const uint8_t*)src_; unit = unit_; total = total_;
+        size_t slab_bytes = kSlabBytes;
+        if (const char* e = getenv("BBHIP_SLAB_KB")) slab_bytes = std::max<size_t>(1, (size_t)atoll(e)) << 10;  // tests
+        per = std::max<int64_t>(1, (int64_t)(slab_bytes / unit));
+        per = std::min(per, total);
+        const int nbuf = total > per ? 2 : 1;
+        for (int i = 0; i < nbuf; ++i) {
+            BB_HIP(hipHostMalloc((void**)&pin[i], (size_t)per * unit, hipHostMallocDefault));
+            BB_HIP(hipMalloc(&dev[i], (size_t)per * unit));
+        }
+        BB_HIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+        return BBH_OK;
+    }
+    void fetch(int64_t first) {  // start moving rows [first, first + per) into buffer (first / per) & 1
+        next = first;
+        if (first >= total) return;
+        const int b = (int)((first / per) & 1);
+        const int64_t m = std::min(per, total - first);
+        pending = std::async(std::launch::async, [this, b, first, m]() -> int {
+            if (hipSetDevice(device) != hipSuccess) return 1;
+            std::memcpy(pin[b], src + (size_t)first * unit, (size_t)m * unit);  // page-in happens here
+            if (hipMemcpyAsync(dev[b], pin[b], (size_t)m * unit, hipMemcpyHostToDevice, cs) != hipSuccess) return 2;
+            return hipStreamSynchronize(cs) == hipSuccess ? 0 : 3;
+        });
+    }
+    // rows [first, first + *m) are resident at the returned device pointer; the following slab
+    // is already on its way when this returns
+    int acquire(int64_t first, const uint8_t** out, int64_t* m) {
+        if (!pending.valid() || next != first) fetch(first);
+        const int rc = pending.get();
+        if (rc != 0) return bb::fail(BBH_ERR_HIP, "host slab transfer failed (stage %d)", rc);
+        *out = dev[(first / per) & 1];
+        *m = std::min(per, total - first);
+        fetch(first + per);
+        return BBH_OK;
+    }
+    ~HostSlabs() {
+        if (pending.valid()) (void)pending.get();
+        for (int i = 0; i < 2; ++i) {
+            if (pin[i]) (void)hipHostFree(pin[i]);
+            if (dev[i]) (void)hipFree(dev[i]);
+        }
+        if (cs) (void)hipStreamDestroy(cs);
+    }
+};
+
 extern "C" int bbh_tree_fit_packed(bbh_tree* t, const uint8_t* rows, int64_t n, int64_t row_stride,
                                    uint32_t* out_leaf, void* stream) {
     if (!t) return bb::fail(BBH_ERR_INVALID, "null tree");
@@ -2177,21 +2245,17 @@ extern "C" int bbh_tree_fit_packed(bbh_tree* t, const uint8_t* rows, int64_t n, 
         if (batch > 0) BB_TRY(run_insert_batched(t, rows, row_stride, n, (uint32_t*)o.dev, batch, s));
         else BB_TRY(run_insert(t, rows, row_stride, nullptr, 0, n, (uint32_t*)o.dev, s));
     } else {
-        // stage host rows through HBM in slabs (PCIe is outside the engine's hot loop)
-        const int64_t slab = std::max<int64_t>(1, (int64_t)(1ull << 30) / row_stride);
-        uint8_t* stage = nullptr;
-        BB_HIP(hipMalloc(&stage, (size_t)std::min(slab, n) * row_stride));
-        int rc = BBH_OK;
-        for (int64_t off = 0; off < n && rc == BBH_OK; off += slab) {
-            const int64_t m = std::min(slab, n - off);
-            hipError_t e = hipMemcpyAsync(stage, rows + off * row_stride, (size_t)m * row_stride, hipMemcpyHostToDevice, s);
-            if (e != hipSuccess) { rc = bb::fail(BBH_ERR_HIP, "H2D: %s", hipGetErrorString(e)); break; }
-            rc = batch > 0 ? run_insert_batched(t, stage, row_stride, m, o.dev ? (uint32_t*)o.dev + off : nullptr, batch, s)
-                           : run_insert(t, stage, row_stride, nullptr, 0, m, o.dev ? (uint32_t*)o.dev + off : nullptr, s);
+        HostSlabs slabs;
+        BB_TRY(slabs.init(t->device, rows, (size_t)row_stride, n));
+        for (int64_t off = 0; off < n;) {
+            const uint8_t* d = nullptr;
+            int64_t m = 0;
+            BB_TRY(slabs.acquire(off, &d, &m));
+            uint32_t* o_off = o.dev ? (uint32_t*)o.dev + off : nullptr;
+            if (batch > 0) BB_TRY(run_insert_batched(t, d, row_stride, m, o_off, batch, s));
+            else BB_TRY(run_insert(t, d, row_stride, nullptr, 0, m, o_off, s));
+            off += m;
         }
-        (void)hipStreamSynchronize(s);
-        (void)hipFree(stage);
-        BB_TRY(rc);
     }
     BB_TRY(o.finish(s));
     BB_HIP(hipStreamSynchronize(s));
@@ -2216,20 +2280,15 @@ extern "C" int bbh_tree_fit_buffers(bbh_tree* t, const void* bufs, int32_t width
     if (bb::is_device_ptr(bufs)) {
         BB_TRY(run_insert(t, nullptr, 0, (const uint8_t*)bufs, width, k, (uint32_t*)o.dev, s));
     } else {
-        const int64_t slab = std::max<int64_t>(1, (int64_t)((1ull << 30) / row_bytes));
-        uint8_t* stage = nullptr;
-        BB_HIP(hipMalloc(&stage, (size_t)std::min(slab, k) * row_bytes));
-        int rc = BBH_OK;
-        for (int64_t off = 0; off < k && rc == BBH_OK; off += slab) {
-            const int64_t m = std::min(slab, k - off);
-            hipError_t e = hipMemcpyAsync(stage, (const uint8_t*)bufs + (size_t)off * row_bytes, (size_t)m * row_bytes,
-                                          hipMemcpyHostToDevice, s);
-            if (e != hipSuccess) { rc = bb::fail(BBH_ERR_HIP, "H2D: %s", hipGetErrorString(e)); break; }
-            rc = run_insert(t, nullptr, 0, stage, width, m, o.dev ? (uint32_t*)o.dev + off : nullptr, s);
+        HostSlabs slabs;
+        BB_TRY(slabs.init(t->device, bufs, row_bytes, k));
+        for (int64_t off = 0; off < k;) {
+            const uint8_t* d = nullptr;
+            int64_t m = 0;
+            BB_TRY(slabs.acquire(off, &d, &m));
+            BB_TRY(run_insert(t, nullptr, 0, d, width, m, o.dev ? (uint32_t*)o.dev + off : nullptr, s));
+            off += m;
         }
-        (void)hipStreamSynchronize(s);
-        (void)hipFree(stage);
-        BB_TRY(rc);
     }
     BB_TRY(o.finish(s));
     BB_HIP(hipStreamSynchronize(s));

@@ -41,10 +41,21 @@ def _same(a: BitBirch, b: BitBirch) -> None:
     ("tolerance-legacy", 0.5, 50, 10_000, "fake"),
     ("diameter", 0.3, 50, 50_000, "sparse"),
     ("diameter", 0.6, 50, 20_000, "sparse"),
+    ("tolerance-radius", 0.65, 8, 152_088, "tiers"),
 ])
 def test_hip_tree_vs_oracle_large(crit, thr, bf, n, kind):
     if kind == "fake":
         fps = np.concatenate([make_fake_fingerprints(min(10_000, n), seed=500 + i) for i in range((n + 9999) // 10_000)])[:n]
+    elif kind == "tiers":
+        # exact duplicates in three weight classes so that uint8, uint16 and uint32 cluster
+        # features meet inside the same leaves and splits (bf 8: a split every few new rows)
+        protos = make_fake_fingerprints(120, seed=77)
+        reps = np.array([70_000] * 2 + [400] * 30 + [1] * 88)
+        # (tolerance-radius: diameter/radius let a huge tight cluster swallow strangers, which
+        # would leave two clusters and no splits)
+        order = np.random.default_rng(5).permutation(np.repeat(np.arange(120), reps))
+        fps = protos[order]
+        assert fps.shape[0] == n
     else:
         fps = sparse_ecfp_like(n, 2048, 99)
     hip = BitBirch(branching_factor=bf, threshold=thr, merge_criterion=crit).fit(fps)
@@ -148,3 +159,23 @@ def test_hip_batch_mode_fake_vs_serial(monkeypatch):
     bat = BitBirch(branching_factor=50, threshold=0.3).fit(fps)
     monkeypatch.delenv("BBHIP_BATCH")
     _same(bat, ser)
+
+
+@pytest.mark.gpu
+def test_hip_streaming_ingest_from_file(tmp_path, monkeypatch):
+    r"""`fit(path)`: the memory-mapped file is streamed through two HBM slabs (pinned bounce
+    buffers, copy stream, helper thread).  Small slabs so that many hand-overs happen; the
+    second call continues the same tree; BitFeature buffers take the same route."""
+    monkeypatch.setenv("BBHIP_SLAB_KB", "300")  # 1200 rows per slab
+    fps = np.concatenate([make_fake_fingerprints(10_000, seed=300 + i) for i in range(3)])
+    f1, f2 = tmp_path / "a.npy", tmp_path / "b.npy"
+    np.save(f1, fps[:17_001])
+    np.save(f2, fps[17_001:])
+    hip = BitBirch(branching_factor=50, threshold=0.3).fit(f1).fit(f2)
+    ora = BitBirch(branching_factor=50, threshold=0.3, _engine_factory=OracleEngine).fit(fps)
+    _same(hip, ora)
+    hip.set_merge("tolerance-diameter", tolerance=0.05)
+    ora.set_merge("tolerance-diameter", tolerance=0.05)
+    hip.refine_inplace([f1, f2], n_largest=2)  # re-inserts ~12 k BitFeature buffers from host tables
+    ora.refine_inplace([f1, f2], n_largest=2)
+    _same(hip, ora)
