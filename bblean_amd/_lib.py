@@ -33,6 +33,7 @@ _PROTOTYPES = {
     "bbh_last_error": (C.c_char_p, []),
     "bbh_device_count": (_int, []),
     "bbh_device_info": (_int, [_int, C.c_char_p, C.c_size_t]),
+    "bbh_trim_cache": (_int, []),
     "bbh_popcount_rows": (_int, [_vp, _i64, _i64, _i64, _vp, _vp]),
     "bbh_jt_arr_vec": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "bbh_jt_best_match": (_int, [_vp, _i64, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),

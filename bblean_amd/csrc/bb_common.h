@@ -58,6 +58,19 @@ inline bool is_device_ptr(const void* p) {
 
 int ensure_device();  // picks device 0 lazily, checks it is gfx950
 
+// ---------------------------------------------------------------------------------------
+// Caching device allocator.  hipFree synchronises the device and hipMalloc of small blocks
+// costs tens of microseconds; a tree owns eight pools that are re-allocated as it grows and a
+// multiround round creates hundreds of trees, so blocks are recycled by size class instead of
+// being returned to the driver (bbh_trim_cache releases them; at most BBHIP_CACHE_MB, default
+// 16 GiB, are retained per process).
+// ---------------------------------------------------------------------------------------
+hipError_t dev_alloc(void** p, size_t bytes);
+void dev_free(void* p);
+void dev_trim();
+template <typename T>
+inline hipError_t dev_alloc(T** p, size_t bytes) { return dev_alloc((void**)p, bytes); }
+
 // Input staged to HBM when the caller handed a host pointer.
 struct DevIn {
     const void* dev = nullptr;
@@ -71,13 +84,13 @@ struct DevIn {
             dev = p;
             return BBH_OK;
         }
-        BB_HIP(hipMalloc(&owned, bytes));
+        BB_HIP(dev_alloc(&owned, bytes));
         BB_HIP(hipMemcpyAsync(owned, p, bytes, hipMemcpyHostToDevice, s));
         dev = owned;
         return BBH_OK;
     }
     ~DevIn() {
-        if (owned) (void)hipFree(owned);
+        if (owned) dev_free(owned);
     }
 };
 
@@ -98,7 +111,7 @@ struct DevOut {
             return BBH_OK;
         }
         host = p;
-        BB_HIP(hipMalloc(&owned, nbytes));
+        BB_HIP(dev_alloc(&owned, nbytes));
         dev = owned;
         return BBH_OK;
     }
@@ -110,7 +123,7 @@ struct DevOut {
         return BBH_OK;
     }
     ~DevOut() {
-        if (owned) (void)hipFree(owned);
+        if (owned) dev_free(owned);
     }
 };
 

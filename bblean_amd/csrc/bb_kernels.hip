@@ -37,6 +37,95 @@ void prof_end(size_t token, hipStream_t s) {
 
 static int g_device_checked = -1;
 
+// ---- caching device allocator (bb_common.h) ------------------------------------------------
+namespace {
+struct DevCache {
+    std::mutex mu;
+    std::map<std::pair<int, size_t>, std::vector<void*>> free_blocks;  // (device, class bytes) -> blocks
+    std::map<void*, std::pair<int, size_t>> live;                      // block -> (device, class bytes)
+    size_t cached = 0;
+    size_t limit = 16ull << 30;
+    DevCache() {
+        if (const char* e = getenv("BBHIP_CACHE_MB")) limit = (size_t)atoll(e) << 20;
+    }
+    static size_t size_class(size_t bytes) {
+        if (bytes <= 512) return 512;
+        if (bytes <= (1u << 20)) {
+            size_t c = 512;
+            while (c < bytes) c <<= 1;
+            return c;
+        }
+        const size_t mb = 1u << 20;
+        return (bytes + mb - 1) / mb * mb;
+    }
+};
+DevCache& dev_cache() {
+    static DevCache* c = new DevCache();  // never destroyed: blocks may outlive static destructors
+    return *c;
+}
+}  // namespace
+
+hipError_t dev_alloc(void** p, size_t bytes) {
+    DevCache& c = dev_cache();
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const size_t cls = DevCache::size_class(bytes);
+    {
+        std::lock_guard<std::mutex> g(c.mu);
+        auto it = c.free_blocks.find({dev, cls});
+        if (it != c.free_blocks.end() && !it->second.empty()) {
+            *p = it->second.back();
+            it->second.pop_back();
+            c.cached -= cls;
+            c.live[*p] = {dev, cls};
+            return hipSuccess;
+        }
+    }
+    e = hipMalloc(p, cls);
+    if (e != hipSuccess) {  // give the cached blocks back to the driver and retry once
+        (void)hipGetLastError();
+        dev_trim();
+        e = hipMalloc(p, cls);
+        if (e != hipSuccess) return e;
+    }
+    std::lock_guard<std::mutex> g(c.mu);
+    c.live[*p] = {dev, cls};
+    return hipSuccess;
+}
+
+void dev_free(void* p) {
+    if (!p) return;
+    DevCache& c = dev_cache();
+    {
+        std::lock_guard<std::mutex> g(c.mu);
+        auto it = c.live.find(p);
+        if (it != c.live.end()) {
+            const std::pair<int, size_t> key = it->second;
+            c.live.erase(it);
+            if (c.cached + key.second <= c.limit) {
+                c.free_blocks[key].push_back(p);
+                c.cached += key.second;
+                return;
+            }
+        }
+    }
+    (void)hipFree(p);
+}
+
+void dev_trim() {
+    DevCache& c = dev_cache();
+    std::vector<void*> victims;
+    {
+        std::lock_guard<std::mutex> g(c.mu);
+        for (auto& kv : c.free_blocks)
+            for (void* b : kv.second) victims.push_back(b);
+        c.free_blocks.clear();
+        c.cached = 0;
+    }
+    for (void* b : victims) (void)hipFree(b);
+}
+
 int ensure_device() {
     if (g_device_checked >= 0) return BBH_OK;
     int n = 0;
@@ -726,6 +815,11 @@ extern "C" int bbh_most_dissimilar(const uint8_t* Y, int64_t n, int64_t nbytes, 
 // misc C ABI
 // =======================================================================================
 extern "C" const char* bbh_last_error(void) { return bb::g_err; }
+
+extern "C" int bbh_trim_cache(void) {
+    bb::dev_trim();
+    return BBH_OK;
+}
 
 extern "C" int bbh_device_count(void) {
     int n = 0;

@@ -1114,9 +1114,8 @@ __device__ __forceinline__ void update_tracker_slow(const KC& k, const Elem& el,
 
 // one tree per workgroup
 template <bool PROF, bool SUB>
-__global__ __launch_bounds__(TB) void k_tree_insert(TreeDev* trees, const uint32_t* gate_nodes, const uint32_t* gate_off,
-                                                    const uint32_t* gate_elems) {
-    extern __shared__ __align__(16) unsigned char smem_raw[];
+__device__ __forceinline__ void tree_insert_body(unsigned char* smem_raw, TreeDev* trees, const uint32_t* gate_nodes,
+                                                 const uint32_t* gate_off, const uint32_t* gate_elems) {
     TreeDev* T = SUB ? trees : trees + blockIdx.x;
     uint32_t* gctr = T->ctr;
     KC k;
@@ -1633,6 +1632,21 @@ __global__ __launch_bounds__(TB) void k_tree_insert(TreeDev* trees, const uint32
 #undef PHASE
 }
 
+// A single tree (or a few) wants the whole register file: one wave per SIMD, no spills.
+template <bool PROF, bool SUB>
+__global__ __launch_bounds__(TB) void k_tree_insert(TreeDev* trees, const uint32_t* gate_nodes, const uint32_t* gate_off,
+                                                    const uint32_t* gate_elems) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    tree_insert_body<PROF, SUB>(smem_raw, trees, gate_nodes, gate_off, gate_elems);
+}
+
+// More trees than compute units: two workgroups per CU (<= 256 VGPRs, 2 waves per SIMD) hide each
+// other's memory and barrier latency.
+__global__ __launch_bounds__(TB, 2) void k_tree_insert_dense(TreeDev* trees) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    tree_insert_body<false, false>(smem_raw, trees, nullptr, nullptr, nullptr);
+}
+
 // =======================================================================================
 // Batch mode (exact, rollback-free): a prefix of the pending fingerprints is routed through the
 // STABLE upper levels of the tree in parallel (k_route), the host admits the longest prefix for
@@ -1828,12 +1842,13 @@ struct bbh_tree {
 
 namespace {
 
+// `used_elems`: the prefix of the old pool that holds live data (only that much is carried over)
 template <typename T>
-int grow_pool(T*& p, size_t old_elems, size_t new_elems) {
+int grow_pool(T*& p, size_t used_elems, size_t new_elems) {
     T* np_ = nullptr;
-    BB_HIP(hipMalloc(&np_, new_elems * sizeof(T) + 64));  // slack: cf_load_raw over-reads 8 bytes
-    if (p && old_elems) BB_HIP(hipMemcpy(np_, p, old_elems * sizeof(T), hipMemcpyDeviceToDevice));
-    if (p) BB_HIP(hipFree(p));
+    BB_HIP(bb::dev_alloc(&np_, new_elems * sizeof(T) + 64));  // slack: cf_load_raw over-reads 8 bytes
+    if (p && used_elems) BB_HIP(hipMemcpy(np_, p, used_elems * sizeof(T), hipMemcpyDeviceToDevice));
+    if (p) bb::dev_free(p);
     p = np_;
     return BBH_OK;
 }
@@ -1842,7 +1857,7 @@ int grow_nodes(bbh_tree* t, uint32_t want) {
     TreeDev& h = t->h;
     if (want <= h.cap_nodes) return BBH_OK;
     const size_t rows = (size_t)h.bf + 1;
-    const size_t oc = h.cap_nodes, nc = want;
+    const size_t oc = std::min<size_t>(h.cap_nodes, h.ctr[C_NODES]), nc = want;  // live nodes only
     BB_TRY(grow_pool(h.node_cent, oc * rows * h.RB, nc * rows * h.RB));
     BB_TRY(grow_pool(h.node_card, oc * rows, nc * rows));
     BB_TRY(grow_pool(h.node_link, oc * rows, nc * rows));
@@ -1856,13 +1871,13 @@ int grow_cf(bbh_tree* t, int tier, uint32_t want) {
     TreeDev& h = t->h;
     const size_t F = (size_t)h.F;
     if (tier == 0 && want > h.cap8) {
-        BB_TRY(grow_pool(h.cf8, (size_t)h.cap8 * F, (size_t)want * F));
+        BB_TRY(grow_pool(h.cf8, (size_t)std::min(h.cap8, h.ctr[C_N8]) * F, (size_t)want * F));
         h.cap8 = want;
     } else if (tier == 1 && want > h.cap16) {
-        BB_TRY(grow_pool(h.cf16, (size_t)h.cap16 * F, (size_t)want * F));
+        BB_TRY(grow_pool(h.cf16, (size_t)std::min(h.cap16, h.ctr[C_N16]) * F, (size_t)want * F));
         h.cap16 = want;
     } else if (tier == 2 && want > h.cap32) {
-        BB_TRY(grow_pool(h.cf32, (size_t)h.cap32 * F, (size_t)want * F));
+        BB_TRY(grow_pool(h.cf32, (size_t)std::min(h.cap32, h.ctr[C_N32]) * F, (size_t)want * F));
         h.cap32 = want;
     }
     return BBH_OK;
@@ -1872,7 +1887,7 @@ void free_pools(bbh_tree* t) {
     TreeDev& h = t->h;
     void* ptrs[] = {h.node_cent, h.node_card, h.node_link, h.node_rm, h.node_hdr, h.scratch_cent, h.cf8, h.cf16, h.cf32};
     for (void* p : ptrs)
-        if (p) (void)hipFree(p);
+        if (p) bb::dev_free(p);
     h.node_cent = nullptr; h.node_card = nullptr; h.node_link = nullptr; h.node_rm = nullptr; h.node_hdr = nullptr;
     h.scratch_cent = nullptr; h.cf8 = nullptr; h.cf16 = nullptr; h.cf32 = nullptr;
     h.cap_nodes = h.cap8 = h.cap16 = h.cap32 = 0;
@@ -1903,13 +1918,13 @@ int init_empty(bbh_tree* t) {
 
 int set_tol(bbh_tree* t, const double* tab, int64_t len) {
     if (t->d_tol) {
-        (void)hipFree(t->d_tol);
+        (void)bb::dev_free(t->d_tol);
         t->d_tol = nullptr;
     }
     t->h.tol_table = nullptr;
     t->h.tol_len = 0;
     if (tab && len > 0) {
-        BB_HIP(hipMalloc(&t->d_tol, (size_t)len * 8));
+        BB_HIP(bb::dev_alloc(&t->d_tol, (size_t)len * 8));
         BB_HIP(hipMemcpy(t->d_tol, tab, (size_t)len * 8, hipMemcpyHostToDevice));
         t->h.tol_table = t->d_tol;
         t->h.tol_len = (int32_t)len;
@@ -1930,16 +1945,33 @@ int configure(bbh_tree* t, int32_t bf, int32_t n_features) {
             if (smem_layout(bf, h.RB, q).total <= 100 * 1024) { nm = q; break; }
     h.use_root_cache = nm;
     t->lds = smem_layout(bf, h.RB, nm).total;
-    if (h.scratch_cent) (void)hipFree(h.scratch_cent);
+    if (h.scratch_cent) bb::dev_free(h.scratch_cent);
     h.scratch_cent = nullptr;
-    BB_HIP(hipMalloc(&h.scratch_cent, ((size_t)bf + 1) * h.RB));
+    BB_HIP(bb::dev_alloc(&h.scratch_cent, ((size_t)bf + 1) * h.RB));
     if (t->lds > 48 * 1024)
     {
         BB_HIP(hipFuncSetAttribute((const void*)k_tree_insert<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->lds));
         BB_HIP(hipFuncSetAttribute((const void*)k_tree_insert<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->lds));
         BB_HIP(hipFuncSetAttribute((const void*)k_tree_insert<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->lds));
+        BB_HIP(hipFuncSetAttribute((const void*)k_tree_insert_dense, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->lds));
     }
     return BBH_OK;
+}
+
+// two workgroups per compute unit pay off once there are more trees than compute units and two
+// of them fit in the CU's 160 KiB of LDS
+static bool dense_launch(size_t n_trees, size_t lds_bytes) {
+    static int cus = -1;
+    static int mode = -1;  // BBHIP_DENSE=0/1 forces the choice (measurements)
+    if (cus < 0) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) ? p.multiProcessorCount : 256;
+        const char* e = getenv("BBHIP_DENSE");
+        mode = e ? atoi(e) : -1;
+    }
+    if (mode >= 0) return mode != 0 && 2 * lds_bytes <= 160 * 1024;
+    return n_trees > (size_t)cus && 2 * lds_bytes <= 160 * 1024;
 }
 
 // One insertion job: a tree and the elements to insert into it.
@@ -1962,7 +1994,7 @@ int run_insert_multi(std::vector<Job>& jobs, hipStream_t s) {
     if (jobs.empty()) return BBH_OK;
     TreeDev* darr = nullptr;
     const bool single = jobs.size() == 1;
-    if (!single) BB_HIP(hipMalloc(&darr, jobs.size() * sizeof(TreeDev)));
+    if (!single) BB_HIP(bb::dev_alloc(&darr, jobs.size() * sizeof(TreeDev)));
     std::vector<TreeDev> harr(jobs.size());
     std::vector<size_t> active;
     int rc = BBH_OK;
@@ -1996,6 +2028,8 @@ int run_insert_multi(std::vector<Job>& jobs, hipStream_t s) {
             if (prof_phases)
                 hipLaunchKernelGGL((k_tree_insert<true, false>), dim3((unsigned)active.size()), dim3(TB), lds, s, dptr,
                                    (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
+            else if (dense_launch(active.size(), lds))
+                hipLaunchKernelGGL(k_tree_insert_dense, dim3((unsigned)active.size()), dim3(TB), lds, s, dptr);
             else
                 hipLaunchKernelGGL((k_tree_insert<false, false>), dim3((unsigned)active.size()), dim3(TB), lds, s, dptr,
                                    (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
@@ -2036,7 +2070,7 @@ int run_insert_multi(std::vector<Job>& jobs, hipStream_t s) {
             }
         }
     }
-    if (darr) (void)hipFree(darr);
+    if (darr) (void)bb::dev_free(darr);
     return rc;
 }
 
@@ -2071,11 +2105,11 @@ int build_chain(bbh_tree* t) {
     }
     const size_t k = t->chain_nodes.size();
     if (k > t->d_chain_cap) {
-        if (t->d_chain_nodes) (void)hipFree(t->d_chain_nodes);
-        if (t->d_chain_rows) (void)hipFree(t->d_chain_rows);
+        if (t->d_chain_nodes) (void)bb::dev_free(t->d_chain_nodes);
+        if (t->d_chain_rows) (void)bb::dev_free(t->d_chain_rows);
         t->d_chain_nodes = t->d_chain_rows = nullptr;
-        BB_HIP(hipMalloc(&t->d_chain_nodes, k * 4));
-        BB_HIP(hipMalloc(&t->d_chain_rows, k * 4));
+        BB_HIP(bb::dev_alloc(&t->d_chain_nodes, k * 4));
+        BB_HIP(bb::dev_alloc(&t->d_chain_rows, k * 4));
         t->d_chain_cap = k;
     }
     if (k) {
@@ -2110,7 +2144,7 @@ extern "C" int bbh_tree_create(bbh_tree** out, int32_t branching_factor, double 
     int rc = configure(t, branching_factor, n_features);
     if (rc == BBH_OK) rc = set_tol(t, tol_table, tol_len);
     if (rc == BBH_OK) {
-        hipError_t e = hipMalloc(&t->d, sizeof(TreeDev));
+        hipError_t e = bb::dev_alloc(&t->d, sizeof(TreeDev));
         if (e != hipSuccess) rc = bb::fail(BBH_ERR_HIP, "hipMalloc: %s", hipGetErrorString(e));
     }
     if (rc == BBH_OK) rc = init_empty(t);
@@ -2125,10 +2159,10 @@ extern "C" int bbh_tree_create(bbh_tree** out, int32_t branching_factor, double 
 extern "C" int bbh_tree_destroy(bbh_tree* t) {
     if (!t) return BBH_OK;
     free_pools(t);
-    if (t->d) (void)hipFree(t->d);
-    if (t->d_tol) (void)hipFree(t->d_tol);
-    if (t->d_chain_nodes) (void)hipFree(t->d_chain_nodes);
-    if (t->d_chain_rows) (void)hipFree(t->d_chain_rows);
+    if (t->d) (void)bb::dev_free(t->d);
+    if (t->d_tol) (void)bb::dev_free(t->d_tol);
+    if (t->d_chain_nodes) (void)bb::dev_free(t->d_chain_nodes);
+    if (t->d_chain_rows) (void)bb::dev_free(t->d_chain_rows);
     delete t;
     return BBH_OK;
 }
@@ -2188,7 +2222,7 @@ struct HostSlabs {
         const int nbuf = total > per ? 2 : 1;
         for (int i = 0; i < nbuf; ++i) {
             BB_HIP(hipHostMalloc((void**)&pin[i], (size_t)per * unit, hipHostMallocDefault));
-            BB_HIP(hipMalloc(&dev[i], (size_t)per * unit));
+            BB_HIP(bb::dev_alloc(&dev[i], (size_t)per * unit));
         }
         BB_HIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
         return BBH_OK;
@@ -2220,7 +2254,7 @@ struct HostSlabs {
         if (pending.valid()) (void)pending.get();
         for (int i = 0; i < 2; ++i) {
             if (pin[i]) (void)hipHostFree(pin[i]);
-            if (dev[i]) (void)hipFree(dev[i]);
+            if (dev[i]) (void)bb::dev_free(dev[i]);
         }
         if (cs) (void)hipStreamDestroy(cs);
     }
@@ -2384,15 +2418,15 @@ extern "C" int bbh_tree_gather_buffers(bbh_tree* t, const int64_t* positions, in
         rows[(size_t)i] = t->chain_rows[(size_t)positions[i]];
     }
     uint32_t *dn = nullptr, *dr = nullptr;
-    BB_HIP(hipMalloc(&dn, (size_t)m * 4));
-    BB_HIP(hipMalloc(&dr, (size_t)m * 4));
+    BB_HIP(bb::dev_alloc(&dn, (size_t)m * 4));
+    BB_HIP(bb::dev_alloc(&dr, (size_t)m * 4));
     int rc = BBH_OK;
     if (hipMemcpy(dn, nodes.data(), (size_t)m * 4, hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(dr, rows.data(), (size_t)m * 4, hipMemcpyHostToDevice) != hipSuccess)
         rc = bb::fail(BBH_ERR_HIP, "gather_buffers: H2D failed");
     if (rc == BBH_OK) rc = gather(t, dn, dr, m, width, out, 0, nullptr, nullptr, nullptr);
-    (void)hipFree(dn);
-    (void)hipFree(dr);
+    (void)bb::dev_free(dn);
+    (void)bb::dev_free(dr);
     return rc;
 }
 

@@ -42,3 +42,10 @@ def hip_extension_is_available() -> bool:
         return True
     except Exception:
         return False
+
+
+def release_device_cache() -> None:
+    r"""Return the device blocks libbbhip keeps for reuse to the driver (``bbh_trim_cache``)."""
+    from bblean_amd import _lib
+
+    _lib.check(_lib.load().bbh_trim_cache())

@@ -95,7 +95,7 @@ def main() -> None:
     ap.add_argument("--cpu-sample", type=int, default=300_000)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--k1-rows", type=int, default=8_000_000)
-    ap.add_argument("--shards", type=int, default=256)
+    ap.add_argument("--shards", type=int, default=512)
     args = ap.parse_args()
 
     import numpy as np

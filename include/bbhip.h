@@ -49,6 +49,10 @@ const char* bbh_last_error(void);
 /* library / device info: writes "gfx950 <name> CUs=.. HBM=.." ; returns device count */
 int bbh_device_count(void);
 int bbh_device_info(int device, char* buf, size_t buflen);
+/* Device blocks released by trees and calls are kept for reuse (hipFree synchronises the device);
+ * this returns them to the driver, e.g. before handing the GPU to another allocator.  No
+ * reference counterpart: NumPy's allocator plays this role there. */
+int bbh_trim_cache(void);
 
 /* ---------------------------------------------------------------------------------- */
 /* Stateless kernels -- one per pybind11 binding of similarity.cpp:473-521             */
