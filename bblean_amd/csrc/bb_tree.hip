@@ -35,6 +35,7 @@
 #include <algorithm>
 #include <cmath>
 #include <future>
+#include <type_traits>
 
 using namespace bbd;
 
@@ -101,7 +102,7 @@ struct TreeDev {
     // state
     uint32_t ctr[C_COUNT];
     unsigned long long stats[8];
-    unsigned long long phase[8];  // shader-clock cycles per phase (thread 0), debug
+    unsigned long long phase[16];  // shader-clock cycles per phase (thread 0), debug; [8..] descent detail
     unsigned long long sphase[8]; // same, inside split_node
     // job of the next launch
     const uint8_t* rows;
@@ -132,37 +133,52 @@ struct Smem {
     uint32_t stats;               // 8 u64
     uint32_t bc;                  // 16 u32 broadcast scratch
     uint32_t planes;              // TW x NPLW x 64 u32 bit-sliced column counters (split)
+    uint32_t ppart;               // 2 x TW x rows u32: per-wave partial intersections of a mirror compare
     uint32_t rc_cent, rc_card, rc_link;  // LDS mirrors of the nodes on the current path (MAXM levels)
     uint32_t total;
 };
 
-__host__ __device__ inline Smem smem_layout(int bf, int RB, int nm) {
-    Smem s{};
+struct SmemCursor {
     uint32_t off = 0;
-    auto take = [&](size_t bytes) {
-        uint32_t o = off;
+    constexpr uint32_t take(size_t bytes) {
+        const uint32_t o = off;
         off += (uint32_t)((bytes + 15) / 16 * 16);
         return o;
-    };
-    const size_t m = (size_t)bf + 1;
-    s.x = take(RB); s.vec = take(RB); s.cA = take(RB); s.cB = take(RB);
-    s.keys = take(2 * m * 8); s.link = take(2 * m * 4);
-    s.i1 = take(m * 4); s.u1 = take(m * 4); s.i2 = take(m * 4); s.u2 = take(m * 4);
-    s.dst = take(m * 4); s.mcard = take(m * 4); s.mlink = take(m * 4); s.mrm = take(m * 32);
-    s.red = take(2 * TW * NRED * 8);
-    s.red32 = take(2 * TW * NRED * 4);
-    s.wbest = take(2 * TW * 8);
-    s.path_node = take(MAXD * 4); s.path_row = take(MAXD * 4); s.path_len = take(MAXD * 4);
-    s.path_slot = take(MAXD * 4); s.path_n = take(MAXD * 4);
-    s.ctr = take(C_COUNT * 4); s.stats = take(8 * 8); s.bc = take(16 * 4);
-    s.planes = take((size_t)TW * NPLW * 64 * 4);
-    if (nm > 0) {
-        s.rc_cent = take((size_t)nm * m * ((size_t)RB + 16));
-        s.rc_card = take((size_t)nm * m * 4);
-        s.rc_link = take((size_t)nm * m * 4);
     }
-    s.total = off;
+};
+
+__host__ __device__ constexpr Smem smem_layout(int bf, int RB, int nm) {
+    Smem s{};
+    SmemCursor c;
+    const size_t m = (size_t)bf + 1;
+    s.x = c.take(RB); s.vec = c.take(RB); s.cA = c.take(RB); s.cB = c.take(RB);
+    s.keys = c.take(2 * m * 8); s.link = c.take(2 * m * 4);
+    s.i1 = c.take(m * 4); s.u1 = c.take(m * 4); s.i2 = c.take(m * 4); s.u2 = c.take(m * 4);
+    s.dst = c.take(m * 4); s.mcard = c.take(m * 4); s.mlink = c.take(m * 4); s.mrm = c.take(m * 32);
+    s.red = c.take(2 * TW * NRED * 8);
+    s.red32 = c.take(2 * TW * NRED * 4);
+    s.wbest = c.take(2 * TW * 8);
+    s.path_node = c.take(MAXD * 4); s.path_row = c.take(MAXD * 4); s.path_len = c.take(MAXD * 4);
+    s.path_slot = c.take(MAXD * 4); s.path_n = c.take(MAXD * 4);
+    s.ctr = c.take(C_COUNT * 4); s.stats = c.take(8 * 8); s.bc = c.take(16 * 4);
+    s.planes = c.take((size_t)TW * NPLW * 64 * 4);
+    s.ppart = c.take(2 * (size_t)TW * m * 4);
+    if (nm > 0) {
+        s.rc_cent = c.take((size_t)nm * m * ((size_t)RB + 16));
+        s.rc_card = c.take((size_t)nm * m * 4);
+        s.rc_link = c.take((size_t)nm * m * 4);
+    }
+    s.total = c.off;
     return s;
+}
+
+// mirrored path levels for a (branching factor, row bytes) pair: as many (<= MAXM) as keep the
+// workgroup's LDS under 100 KiB; only 2048-bit rows are mirrored
+__host__ __device__ constexpr int mirror_levels(int bf, int RB) {
+    if (RB != 256) return 0;
+    for (int q = MAXM; q >= 1; --q)
+        if (smem_layout(bf, RB, q).total <= 100 * 1024) return q;
+    return 0;
 }
 
 #if defined(__HIPCC__)
@@ -211,25 +227,38 @@ __device__ __forceinline__ u64 wmax64(u64 v) {
     return ab > cd ? ab : cd;
 }
 
-// uniform kernel context: plain values, fully scalarised after inlining
-struct KC {
+// uniform kernel context: plain values, fully scalarised after inlining.  Two flavours with the
+// same member names: KC carries the tree's shape (branching factor, row width, LDS layout) as
+// run-time values; KCFix<BF, NF> has them as compile-time constants, which frees ~45 scalar
+// registers, turns every LDS offset into an instruction immediate and folds the shape-dependent
+// branches and loops.  The device code is templated on the context type.
+struct KCBase {
     uint8_t* cent; uint32_t* card; uint32_t* link; RowMeta* rm; NodeHdr* hdr; uint8_t* scratch;
     uint8_t* cf8; uint16_t* cf16; uint32_t* cf32;
     const uint8_t* bufs; int width;
+    int crit, tol_len; double thr, tolerance; const double* tol;
+    LA unsigned char* L;
+};
+struct KC : KCBase {
     int F, nb, RB, RBc, RBS;
     uint32_t rows, bf;
-    int crit, tol_len; double thr, tolerance; const double* tol;
     int nm;  // mirrored levels
-    LA unsigned char* L;
     Smem o;
+};
+template <int BF, int NF>
+struct KCFix : KCBase {
+    static constexpr int F = NF, nb = NF / 8, RB = (NF / 8 + 15) / 16 * 16, RBc = RB / 16, RBS = RB + 16;
+    static constexpr uint32_t rows = BF + 1, bf = BF;
+    static constexpr int nm = mirror_levels(BF, RB);
+    static constexpr Smem o = smem_layout(BF, RB, nm);
 };
 struct Elem {  // the element being inserted (uniform)
     long long idx; uint32_t nS; u64 s1S, s2S; uint32_t pcx;
 };
 
 // ---- block reduction of NV u64 values to every thread, uniform result (one barrier) ------
-template <int NV>
-__device__ __forceinline__ void block_sum(const KC& k, int& red_slot, u64 (&v)[NV]) {
+template <int NV, class KCt>
+__device__ __forceinline__ void block_sum(const KCt& k, int& red_slot, u64 (&v)[NV]) {
     LA u64* buf = lds<u64>(k.L, k.o.red) + red_slot * TW * NRED;
     red_slot ^= 1;
     const int w = threadIdx.x >> 6;
@@ -250,7 +279,8 @@ __device__ __forceinline__ void block_sum(const KC& k, int& red_slot, u64 (&v)[N
 
 // The hot-path reduction: one dot product (64-bit only when it can exceed 32 bits) and up to
 // 1 + MAXFAST popcounts (always < 2^14), one barrier.  Results are wave-uniform.
-__device__ __forceinline__ void block_sum_fused(const KC& k, int& red_slot, bool wide_dot, u64& dot,
+template <class KCt>
+__device__ __forceinline__ void block_sum_fused(const KCt& k, int& red_slot, bool wide_dot, u64& dot,
                                                 uint32_t (&pc)[1 + MAXFAST], int npc) {
     LA u64* b64 = lds<u64>(k.L, k.o.red) + red_slot * TW * NRED;
     LA uint32_t* b32 = lds<uint32_t>(k.L, k.o.red32) + red_slot * TW * NRED;
@@ -283,7 +313,8 @@ __device__ __forceinline__ void block_sum_fused(const KC& k, int& red_slot, bool
 }
 
 // ---- cluster-feature access: 8 consecutive features -----------------------------------
-__device__ __forceinline__ void cf_load8(const KC& k, uint32_t slotw, int b, uint32_t v[8]) {
+template <class KCt>
+__device__ __forceinline__ void cf_load8(const KCt& k, uint32_t slotw, int b, uint32_t v[8]) {
     const uint32_t tier = slotw >> 30;
     const size_t idx = (size_t)(slotw & 0x3FFFFFFFu) * (size_t)k.F + (size_t)b * 8;
     if (tier == 0) {
@@ -306,7 +337,8 @@ __device__ __forceinline__ void cf_load8(const KC& k, uint32_t slotw, int b, uin
 // the branch's join): always two 16-byte loads, the second one only meaningful for cf32 and
 // pointed at the same line otherwise.  cf8 rows are 8-byte aligned and over-read by 8 bytes
 // (the pools carry 64 bytes of slack; amdhsa runs with unaligned access enabled).
-__device__ __forceinline__ void cf_load_raw(const KC& k, uint32_t slotw, int b, u32x4_t (&raw)[2]) {
+template <class KCt>
+__device__ __forceinline__ void cf_load_raw(const KCt& k, uint32_t slotw, int b, u32x4_t (&raw)[2]) {
     const uint32_t tier = slotw >> 30;
     // mask arithmetic, not ?: - the compiler turns a three-way pointer select into a table in scratch
     const u64 m0 = 0ull - (u64)(tier == 0), m1 = 0ull - (u64)(tier == 1), m2 = 0ull - (u64)(tier >= 2);
@@ -330,7 +362,8 @@ __device__ __forceinline__ void cf_unpack_raw(uint32_t tier, const u32x4_t (&raw
     }
 }
 
-__device__ __forceinline__ void cf_store8(const KC& k, uint32_t slotw, int b, const uint32_t v[8]) {
+template <class KCt>
+__device__ __forceinline__ void cf_store8(const KCt& k, uint32_t slotw, int b, const uint32_t v[8]) {
     const uint32_t tier = slotw >> 30;
     const size_t idx = (size_t)(slotw & 0x3FFFFFFFu) * (size_t)k.F + (size_t)b * 8;
     if (tier == 0) {
@@ -353,7 +386,8 @@ __device__ __forceinline__ void cf_store8(const KC& k, uint32_t slotw, int b, co
 }
 
 // tracking BitFeatures always live in cf32: no tier dispatch on the hot path
-__device__ __forceinline__ void cf32_load8(const KC& k, uint32_t slotw, int b, uint32_t v[8]) {
+template <class KCt>
+__device__ __forceinline__ void cf32_load8(const KCt& k, uint32_t slotw, int b, uint32_t v[8]) {
     const size_t idx = (size_t)(slotw & 0x3FFFFFFFu) * (size_t)k.F + (size_t)b * 8;
     const u32x4_t q0 = ldg<u32x4_t>(k.cf32 + idx), q1 = ldg<u32x4_t>(k.cf32 + idx + 4);
     v[0] = q0.x; v[1] = q0.y; v[2] = q0.z; v[3] = q0.w;
@@ -361,7 +395,8 @@ __device__ __forceinline__ void cf32_load8(const KC& k, uint32_t slotw, int b, u
 }
 
 // linear-sum values of the element being inserted for features b*8 .. b*8+7
-__device__ __forceinline__ void elem_cols(const KC& k, const Elem& el, int b, uint32_t v[8]) {
+template <class KCt>
+__device__ __forceinline__ void elem_cols(const KCt& k, const Elem& el, int b, uint32_t v[8]) {
     if (k.bufs == nullptr) {  // fingerprint: bits of the packed row, MSB first
         const uint32_t xb = lds<uint8_t>(k.L, k.o.x)[b];
 #pragma unroll
@@ -402,7 +437,8 @@ __device__ __forceinline__ uint32_t tier_for(u64 n) { return n <= 255 ? 0u : (n 
 __device__ __forceinline__ int ctr_for_tier(uint32_t tier) { return tier == 0 ? C_N8 : (tier == 1 ? C_N16 : C_N32); }
 
 // popcount of an RB-byte vector in LDS (every wave computes it redundantly; uniform result)
-__device__ __forceinline__ uint32_t lds_vec_popcount(const KC& k, uint32_t off) {
+template <class KCt>
+__device__ __forceinline__ uint32_t lds_vec_popcount(const KCt& k, uint32_t off) {
     uint32_t p = 0;
     for (int ch = threadIdx.x & 63; ch < k.RBc; ch += 64) p += popc4v(lds<u32x4_t>(k.L, off)[ch]);
     return wsum32(p);
@@ -428,8 +464,8 @@ __device__ __forceinline__ bool cand_better(uint32_t ai, uint32_t au, uint32_t a
 // waiting for the node's length (rows >= len are masked) so header and rows arrive in the
 // same memory round trip; popcounts of 16 lanes meet by DPP, the 4 row groups of a wave by
 // readlane, the 4 waves through 32 bytes of LDS and one barrier.
-template <bool ROOT, bool MINMODE>
-__device__ __forceinline__ Cand node_best(const KC& k, int& cmp_par, uint32_t nd, int known_len, uint32_t vec_off,
+template <bool ROOT, bool MINMODE, class KCt>
+__device__ __forceinline__ Cand node_best(const KCt& k, int& cmp_par, uint32_t nd, int known_len, uint32_t vec_off,
                                           uint32_t vec_pc, bool want_counts, bool second, bool want_link,
                                           uint32_t* out_len, uint32_t* out_leaf, uint32_t mslot = 0, bool fill = false,
                                           bool* out_any_card = nullptr) {
@@ -591,8 +627,86 @@ __device__ __forceinline__ Cand node_best(const KC& k, int& cmp_par, uint32_t nd
     return best;
 }
 
+// ---- the same comparison for a node that sits in LDS mirror `mslot` (2048-bit rows) ---------
+// One row per LANE and a quarter of the row (16 dwords) per WAVE: 4 LDS reads + 16 AND/BCNT per
+// lane and no cross-lane reduction at all; the four partial intersections of a row meet through
+// LDS (one barrier), then every wave redundantly forms the candidates and reduces them
+// (DPP butterfly inside the 16-lane rows, readlane across them), so the result is uniform across
+// the block without a second barrier.  ~4x fewer instructions than the 16-lanes-per-row layout
+// that suits coalesced HBM reads.
+template <bool MINMODE, class KCt>
+__device__ __forceinline__ Cand node_best_mirror(const KCt& k, int& cmp_par, uint32_t len, uint32_t vec_off, uint32_t vec_pc,
+                                                 bool want_counts, bool second, uint32_t mslot, bool* out_any_card) {
+    const uint32_t mrow0 = mslot * k.rows;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    cmp_par ^= 1;
+    LA uint32_t* pp = lds<uint32_t>(k.L, k.o.ppart) + (uint32_t)cmp_par * TW * k.rows;
+    LA uint32_t* s_i = lds<uint32_t>(k.L, second ? k.o.i2 : k.o.i1);
+    LA uint32_t* s_u = lds<uint32_t>(k.L, second ? k.o.u2 : k.o.u1);
+    // this wave's 64 bytes of the query vector (same address in every lane: LDS broadcast)
+    u32x4_t xv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xv[i] = *(LA u32x4_t*)(k.L + vec_off + wave * 64 + i * 16);
+    const uint32_t last = len - 1;  // len >= 1
+    for (uint32_t r0 = 0; r0 < len; r0 += 64) {
+        const uint32_t r = r0 + lane;
+        const uint32_t rc = r < last ? r : last;
+        const uint32_t base = k.o.rc_cent + (mrow0 + rc) * k.RBS + wave * 64;
+        u32x4_t d[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) d[i] = *(LA u32x4_t*)(k.L + base + i * 16);
+        uint32_t part = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) part += popc4v(d[i] & xv[i]);
+        if (r < len) pp[wave * k.rows + r] = part;
+    }
+    // a full barrier: it also orders the previous insertion's HBM stores before the RowMeta read
+    // that follows the compare (an LDS-only barrier measured no faster)
+    __syncthreads();
+    uint32_t biu = MINMODE ? (0xFFFFu << 16 | 1u) : 1u, br = NONE;  // best of this lane: inter << 16 | union, row
+    bool anyc = false;
+    for (uint32_t r0 = 0; r0 < len; r0 += 64) {
+        const uint32_t r = r0 + lane;
+        const uint32_t rc = r < last ? r : last;
+        uint32_t inter = 0;
+#pragma unroll
+        for (int w = 0; w < TW; ++w) inter += pp[w * k.rows + rc];
+        const uint32_t card = lds<uint32_t>(k.L, k.o.rc_card)[mrow0 + rc];
+        uint32_t un = card + vec_pc - inter;
+        if (want_counts && wave == 0 && r < len) { s_i[r] = inter; s_u[r] = un; }
+        un = un < 1u ? 1u : un;
+        anyc = anyc || (r < len && card != 0);
+        const bool take = r < len && cand_better<MINMODE>(inter, un, r, biu >> 16, biu & 0xFFFFu, br);
+        biu = take ? (inter << 16 | un) : biu;
+        br = take ? r : br;
+    }
+    // 16-lane rows: rotate-and-keep-better butterfly leaves the row's best in all of its lanes
+#define BB_STEP(N)                                                                                   \
+    {                                                                                                \
+        const uint32_t oiu = row_ror<N>(biu), orr = row_ror<N>(br);                                  \
+        const bool take = cand_better<MINMODE>(oiu >> 16, oiu & 0xFFFFu, orr, biu >> 16, biu & 0xFFFFu, br); \
+        biu = take ? oiu : biu;                                                                      \
+        br = take ? orr : br;                                                                        \
+    }
+    BB_STEP(8) BB_STEP(4) BB_STEP(2) BB_STEP(1)
+#undef BB_STEP
+    uint32_t wiu = rdlane(biu, 0), wr = rdlane(br, 0);
+#pragma unroll
+    for (int q = 16; q < 64; q += 16) {
+        const uint32_t ciu = rdlane(biu, q), cr = rdlane(br, q);
+        if (cand_better<MINMODE>(ciu >> 16, ciu & 0xFFFFu, cr, wiu >> 16, wiu & 0xFFFFu, wr)) { wiu = ciu; wr = cr; }
+    }
+    if (out_any_card) *out_any_card = __ballot(anyc) != 0ull;
+    Cand best;
+    best.i = wiu >> 16;
+    best.u = wiu & 0xFFFFu;
+    best.r = wr;
+    return best;
+}
+
 // write one node row: centroid (from LDS), popcount, link, meta
-__device__ __forceinline__ void node_put_row(const KC& k, uint32_t nd, uint32_t row, uint32_t cent_off, uint32_t card,
+template <class KCt>
+__device__ __forceinline__ void node_put_row(const KCt& k, uint32_t nd, uint32_t row, uint32_t cent_off, uint32_t card,
                                              uint32_t link, uint32_t sub, uint32_t n, uint32_t slot, u64 s1, u64 s2) {
     const size_t m = (size_t)nd * k.rows + row;
     for (int ch = threadIdx.x; ch < k.RBc; ch += TB)
@@ -609,7 +723,8 @@ __device__ __forceinline__ void node_put_row(const KC& k, uint32_t nd, uint32_t 
 }
 
 // ---- radius complement terms (similarity.py:192-202) on CF(slot) [+ element] -----------
-__device__ __forceinline__ void radius_terms(const KC& k, const Elem& el, int& red_slot, uint32_t slotw, bool add_elem,
+template <class KCt>
+__device__ __forceinline__ void radius_terms(const KCt& k, const Elem& el, int& red_slot, uint32_t slotw, bool add_elem,
                                              u64 n, u64& sc, u64& sq) {
     u64 acc[2] = {0, 0};
     for (int b = threadIdx.x; b < k.nb; b += TB) {
@@ -639,14 +754,16 @@ __device__ __forceinline__ double radius_compl(u64 s1, u64 s2, u64 sc, u64 sq, u
     return (jt1 * (double)(n + 1) - jt * (double)(n - 1)) / 2;
 }
 
-__device__ __forceinline__ double tol_lookup(const KC& k, u64 old_n) {
+template <class KCt>
+__device__ __forceinline__ double tol_lookup(const KCt& k, u64 old_n) {
     if (k.tol == nullptr || old_n >= (u64)k.tol_len) return 0.0;
     return ldg<double>(k.tol + old_n);
 }
 
 // merge_accept_fn(threshold, new_ls, new_n, old_ls, nom_ls, old_n, nom_n) of _merges.py,
 // on exact moments.  Uniform across the block.
-__device__ __forceinline__ bool merge_accept(const KC& k, const Elem& el, int& red_slot, uint32_t slotT, u64 nT, u64 s1T,
+template <class KCt>
+__device__ __forceinline__ bool merge_accept(const KCt& k, const Elem& el, int& red_slot, uint32_t slotT, u64 nT, u64 s1T,
                                              u64 s2T, u64 new_n, u64 s1n, u64 s2n) {
     const double thr = k.thr;
     switch (k.crit) {
@@ -689,8 +806,8 @@ __device__ __forceinline__ bool merge_accept(const KC& k, const Elem& el, int& r
 // Allocation of ids / slots / nodes.  Single-tree launches own the tree: the counters are
 // wave-uniform registers.  In SUB (concurrent gates of one tree) mode the counters live in the
 // TreeDev and are bumped with one device-scope atomic by thread 0, broadcast through LDS.
-template <bool SUB>
-__device__ __forceinline__ uint32_t alloc_n(const KC& k, uint32_t& reg, uint32_t* gctr, uint32_t cnt, int bc_slot) {
+template <bool SUB, class KCt>
+__device__ __forceinline__ uint32_t alloc_n(const KCt& k, uint32_t& reg, uint32_t* gctr, uint32_t cnt, int bc_slot) {
     if constexpr (!SUB) {
         const uint32_t r = reg;
         reg += cnt;
@@ -712,8 +829,8 @@ __device__ __forceinline__ uint32_t alloc_n(const KC& k, uint32_t& reg, uint32_t
 // over the count's NPW bit planes.  The four partial counts meet in LDS, are added with full
 // adders (NPT planes) and compared with ceil(m/2) plane by plane, which leaves the packed
 // majority dword directly.  Needs m <= 4 * (2^NPW - 1) and m < 2^NPT.
-template <int NPW, int NPT>
-__device__ __forceinline__ void majority_rows(const KC& k, bool lm, uint32_t mrow0, const uint8_t* cent, uint32_t m) {
+template <int NPW, int NPT, class KCt>
+__device__ __forceinline__ void majority_rows(const KCt& k, bool lm, uint32_t mrow0, const uint8_t* cent, uint32_t m) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int RBdw = k.RB / 4;
     const uint32_t half = (m + 1) >> 1;
@@ -780,8 +897,8 @@ __device__ __forceinline__ void majority_rows(const KC& k, bool lm, uint32_t mro
 // Splits node `nd` (len = bf+1 rows).  Leaves the two tracking BitFeatures' centroids in
 // LDS (o.cA / o.cB) and publishes through bc: [0]=node1 [3]=cardA [4]=cardB [7]=nA [8]=nB
 // [9]=slotA [10]=slotB [11]=n overflow flag.
-template <bool SUB, bool PROF>
-__device__ __forceinline__ void split_node(const KC& k, const Elem& el, int& red_slot, int& cmp_par, uint32_t nd, uint32_t ms,
+template <bool SUB, bool PROF, class KCt>
+__device__ __forceinline__ void split_node(const KCt& k, const Elem& el, int& red_slot, int& cmp_par, uint32_t nd, uint32_t ms,
                                            bool ms_valid, uint32_t trk_slot, uint32_t& cN, uint32_t& c32, uint32_t& cFirst,
                                            uint32_t* gctr, u64 (&sph)[8]) {
     // ms: LDS mirror slot to work in (2048-bit rows only); ms_valid: it already holds nd's rows.
@@ -844,13 +961,14 @@ __device__ __forceinline__ void split_node(const KC& k, const Elem& el, int& red
     //    argmin; 4. similarities to fp2
     uint32_t f1;
     if (lm) {
-        f1 = node_best<true, true>(k, cmp_par, nd, (int)m, k.o.vec, pc, false, false, false, nullptr, nullptr, ms).r;
+        f1 = node_best_mirror<true>(k, cmp_par, m, k.o.vec, pc, false, false, ms, nullptr).r;
         for (int ch = tid; ch < k.RBc; ch += TB) vec[ch] = *(LA u32x4_t*)(k.L + k.o.rc_cent + (mrow0 + f1) * k.RBS + ch * 16);
         __syncthreads();
-        const uint32_t f2 = node_best<true, true>(k, cmp_par, nd, (int)m, k.o.vec, uni(mcard[f1]), true, false, false, nullptr, nullptr, ms).r;
+        const uint32_t f2 = node_best_mirror<true>(k, cmp_par, m, k.o.vec, uni(mcard[f1]), true, false, ms, nullptr).r;
         for (int ch = tid; ch < k.RBc; ch += TB) vec[ch] = *(LA u32x4_t*)(k.L + k.o.rc_cent + (mrow0 + f2) * k.RBS + ch * 16);
         __syncthreads();
-        (void)node_best<true, true>(k, cmp_par, nd, (int)m, k.o.vec, uni(mcard[f2]), true, true, false, nullptr, nullptr, ms);
+        (void)node_best_mirror<true>(k, cmp_par, m, k.o.vec, uni(mcard[f2]), true, true, ms, nullptr);
+        __syncthreads();  // the counts of the last pass are written after its internal barrier
     } else {
         f1 = node_best<false, true>(k, cmp_par, nd, (int)m, k.o.vec, pc, false, false, false, nullptr, nullptr).r;
         for (int ch = tid; ch < k.RBc; ch += TB) vec[ch] = ldg<u32x4_t>(cent + (size_t)f1 * k.RB + (size_t)ch * 16);
@@ -1085,7 +1203,8 @@ __device__ __forceinline__ void split_node(const KC& k, const Elem& el, int& red
 }
 
 // CF += element on one ancestor row (closest_subcluster.update, bitbirch.py:352-357); slow path
-__device__ __forceinline__ void update_tracker_slow(const KC& k, const Elem& el, int& red_slot, int lvl, int& stop) {
+template <class KCt>
+__device__ __forceinline__ void update_tracker_slow(const KCt& k, const Elem& el, int& red_slot, int lvl, int& stop) {
     const int tid = threadIdx.x;
     const uint32_t P = uni(lds<uint32_t>(k.L, k.o.path_node)[lvl]), jp = uni(lds<uint32_t>(k.L, k.o.path_row)[lvl]);
     const size_t pm = (size_t)P * k.rows + jp;
@@ -1113,21 +1232,23 @@ __device__ __forceinline__ void update_tracker_slow(const KC& k, const Elem& el,
 }
 
 // one tree per workgroup
-template <bool PROF, bool SUB>
+template <bool PROF, bool SUB, class KCt>
 __device__ __forceinline__ void tree_insert_body(unsigned char* smem_raw, TreeDev* trees, const uint32_t* gate_nodes,
                                                  const uint32_t* gate_off, const uint32_t* gate_elems) {
     TreeDev* T = SUB ? trees : trees + blockIdx.x;
     uint32_t* gctr = T->ctr;
-    KC k;
+    KCt k;
     k.cent = T->node_cent; k.card = T->node_card; k.link = T->node_link; k.rm = T->node_rm; k.hdr = T->node_hdr;
     k.scratch = T->scratch_cent; k.cf8 = T->cf8; k.cf16 = T->cf16; k.cf32 = T->cf32;
     k.bufs = T->bufs; k.width = (int)uni((uint32_t)T->width);
-    k.F = (int)uni((uint32_t)T->F); k.nb = (int)uni((uint32_t)T->nbytes); k.RB = (int)uni((uint32_t)T->RB); k.RBc = k.RB / 16; k.RBS = k.RB + 16;
-    k.bf = uni((uint32_t)T->bf); k.rows = k.bf + 1;
     k.crit = (int)uni((uint32_t)T->crit); k.tol_len = (int)uni((uint32_t)T->tol_len); k.thr = T->thr; k.tolerance = T->tolerance; k.tol = T->tol_table;
-    k.nm = (int)uni((uint32_t)T->use_root_cache);  // number of mirrored path levels
     k.L = (LA unsigned char*)smem_raw;
-    k.o = smem_layout((int)k.bf, k.RB, k.nm);
+    if constexpr (std::is_same<KCt, KC>::value) {  // shape of the tree as run-time values
+        k.F = (int)uni((uint32_t)T->F); k.nb = (int)uni((uint32_t)T->nbytes); k.RB = (int)uni((uint32_t)T->RB); k.RBc = k.RB / 16; k.RBS = k.RB + 16;
+        k.bf = uni((uint32_t)T->bf); k.rows = k.bf + 1;
+        k.nm = (int)uni((uint32_t)T->use_root_cache);  // number of mirrored path levels
+        k.o = smem_layout((int)k.bf, k.RB, k.nm);
+    }
     const uint8_t* in_rows = T->rows;
     const long long row_stride = T->row_stride;
     const uint32_t g_off = SUB ? uni(gate_off[blockIdx.x]) : 0u;
@@ -1162,7 +1283,7 @@ __device__ __forceinline__ void tree_insert_body(unsigned char* smem_raw, TreeDe
     bool mir_zero[MAXM];  // every centroid of the mirrored node is all-zero: similarity 0 to anything
 #pragma unroll
     for (int q = 0; q < MAXM; ++q) { mir_node[q] = NONE; mir_len[q] = 0; mir_leaf[q] = 0; mir_zero[q] = false; }
-    u64 ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    u64 ph[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     u64 sph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     u64 tmark = PROF ? __builtin_amdgcn_s_memtime() : 0;
 #define PHASE(i) do { if constexpr (PROF) { const u64 _n = __builtin_amdgcn_s_memtime(); ph[i] += _n - tmark; tmark = _n; } } while (0)
@@ -1298,8 +1419,7 @@ __device__ __forceinline__ void tree_insert_body(unsigned char* smem_raw, TreeDe
                     j = 0;
                     link = uni(lds<uint32_t>(k.L, k.o.rc_link)[(uint32_t)depth * k.rows]);
                 } else if (hit) {
-                    best = node_best<true, false>(k, cmp_par, nd, (int)len, k.o.x, el.pcx, false, false, false, nullptr, nullptr,
-                                                  (uint32_t)depth, false, &anyc);
+                    best = node_best_mirror<false>(k, cmp_par, len, k.o.x, el.pcx, false, false, (uint32_t)depth, &anyc);
                     j = best.r;
                     link = uni(lds<uint32_t>(k.L, k.o.rc_link)[(uint32_t)depth * k.rows + j]);
 #pragma unroll
@@ -1316,6 +1436,12 @@ __device__ __forceinline__ void tree_insert_body(unsigned char* smem_raw, TreeDe
                         for (int q = 0; q < MAXM; ++q)
                             if (depth == q) { mir_node[q] = nd; mir_len[q] = len; mir_leaf[q] = leaf; mir_zero[q] = !anyc; }
                     }
+                }
+                if constexpr (PROF) {  // [8]/[9]/[10]: cycles of zero-skip / hit / miss levels, [11..13]: their counts
+                    const int cls = (hit && zero) ? 0 : (hit ? 1 : 2);
+                    const u64 _n = __builtin_amdgcn_s_memtime();
+                    ph[8 + cls] += _n - tmark;
+                    ph[11 + cls] += 1;
                 }
                 if (depth == 0) PHASE(6); else PHASE(7);
                 if (depth > 0) {  // the previous level's RowMeta has arrived by now
@@ -1626,26 +1752,33 @@ __device__ __forceinline__ void tree_insert_body(unsigned char* smem_raw, TreeDe
         if (tid == 0) {
             T->processed = e;
             T->stop_reason = stop;
-            if constexpr (PROF) for (int i = 0; i < 8; ++i) { T->phase[i] += ph[i]; T->sphase[i] += sph[i]; }
+            if constexpr (PROF) {
+                for (int i = 0; i < 16; ++i) T->phase[i] += ph[i];
+                for (int i = 0; i < 8; ++i) T->sphase[i] += sph[i];
+            }
         }
     }
 #undef PHASE
 }
 
 // A single tree (or a few) wants the whole register file: one wave per SIMD, no spills.
-template <bool PROF, bool SUB>
+template <bool PROF, bool SUB, class KCt = KC>
 __global__ __launch_bounds__(TB) void k_tree_insert(TreeDev* trees, const uint32_t* gate_nodes, const uint32_t* gate_off,
                                                     const uint32_t* gate_elems) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    tree_insert_body<PROF, SUB>(smem_raw, trees, gate_nodes, gate_off, gate_elems);
+    tree_insert_body<PROF, SUB, KCt>(smem_raw, trees, gate_nodes, gate_off, gate_elems);
 }
 
 // More trees than compute units: two workgroups per CU (<= 256 VGPRs, 2 waves per SIMD) hide each
 // other's memory and barrier latency.
+template <class KCt = KC>
 __global__ __launch_bounds__(TB, 2) void k_tree_insert_dense(TreeDev* trees) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    tree_insert_body<false, false>(smem_raw, trees, nullptr, nullptr, nullptr);
+    tree_insert_body<false, false, KCt>(smem_raw, trees, nullptr, nullptr, nullptr);
 }
+
+// shapes with a specialised kernel (KCFix): the benchmark / test default and the CLI default
+using KC50 = KCFix<50, 2048>;
 
 // =======================================================================================
 // Batch mode (exact, rollback-free): a prefix of the pending fingerprints is routed through the
@@ -1939,10 +2072,7 @@ int configure(bbh_tree* t, int32_t bf, int32_t n_features) {
     h.nbytes = n_features / 8;
     h.RB = (h.nbytes + 15) / 16 * 16;
     // LDS mirrors of the nodes on the current path: as many levels (<= MAXM) as fit comfortably
-    int nm = 0;
-    if (h.RB == 256)
-        for (int q = MAXM; q >= 1; --q)
-            if (smem_layout(bf, h.RB, q).total <= 100 * 1024) { nm = q; break; }
+    const int nm = mirror_levels(bf, h.RB);
     h.use_root_cache = nm;
     t->lds = smem_layout(bf, h.RB, nm).total;
     if (h.scratch_cent) bb::dev_free(h.scratch_cent);
@@ -1953,7 +2083,10 @@ int configure(bbh_tree* t, int32_t bf, int32_t n_features) {
         BB_HIP(hipFuncSetAttribute((const void*)k_tree_insert<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->lds));
         BB_HIP(hipFuncSetAttribute((const void*)k_tree_insert<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->lds));
         BB_HIP(hipFuncSetAttribute((const void*)k_tree_insert<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->lds));
-        BB_HIP(hipFuncSetAttribute((const void*)k_tree_insert_dense, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->lds));
+        BB_HIP(hipFuncSetAttribute((const void*)k_tree_insert_dense<KC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->lds));
+        BB_HIP(hipFuncSetAttribute((const void*)k_tree_insert<false, false, KC50>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->lds));
+        BB_HIP(hipFuncSetAttribute((const void*)k_tree_insert_dense<KC50>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->lds));
+        BB_HIP(hipFuncSetAttribute((const void*)k_tree_insert<true, false, KC50>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->lds));
     }
     return BBH_OK;
 }
@@ -2025,14 +2158,31 @@ int run_insert_multi(std::vector<Job>& jobs, hipStream_t s) {
         {
             bb::ProfScope ps("tree_insert", s);
             static const bool prof_phases = getenv("BBHIP_PHASES") != nullptr;
-            if (prof_phases)
+            // trees of the benchmark / default shape run the kernel compiled for that shape
+            static const bool no_fix = getenv("BBHIP_NO_FIXED_SHAPE") != nullptr;
+            bool all50 = !no_fix;
+            for (size_t a = 0; a < active.size() && all50; ++a) {
+                const TreeDev& q = jobs[active[a]].t->h;
+                all50 = q.bf == 50 && q.F == 2048;
+            }
+            if (prof_phases && all50)
+                hipLaunchKernelGGL((k_tree_insert<true, false, KC50>), dim3((unsigned)active.size()), dim3(TB), lds, s, dptr,
+                                   (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
+            else if (prof_phases)
                 hipLaunchKernelGGL((k_tree_insert<true, false>), dim3((unsigned)active.size()), dim3(TB), lds, s, dptr,
                                    (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
-            else if (dense_launch(active.size(), lds))
-                hipLaunchKernelGGL(k_tree_insert_dense, dim3((unsigned)active.size()), dim3(TB), lds, s, dptr);
-            else
-                hipLaunchKernelGGL((k_tree_insert<false, false>), dim3((unsigned)active.size()), dim3(TB), lds, s, dptr,
-                                   (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
+            else {
+                const bool dense = dense_launch(active.size(), lds);
+                const dim3 grid((unsigned)active.size()), block(TB);
+                if (dense && all50) hipLaunchKernelGGL(k_tree_insert_dense<KC50>, grid, block, lds, s, dptr);
+                else if (dense) hipLaunchKernelGGL(k_tree_insert_dense<KC>, grid, block, lds, s, dptr);
+                else if (all50)
+                    hipLaunchKernelGGL((k_tree_insert<false, false, KC50>), grid, block, lds, s, dptr, (const uint32_t*)nullptr,
+                                       (const uint32_t*)nullptr, (const uint32_t*)nullptr);
+                else
+                    hipLaunchKernelGGL((k_tree_insert<false, false, KC>), grid, block, lds, s, dptr, (const uint32_t*)nullptr,
+                                       (const uint32_t*)nullptr, (const uint32_t*)nullptr);
+            }
             e = hipGetLastError();
         }
         if (e == hipSuccess) e = hipMemcpyAsync(harr.data(), dptr, active.size() * sizeof(TreeDev), hipMemcpyDeviceToHost, s);
@@ -2438,6 +2588,11 @@ extern "C" int bbh_tree_stats(bbh_tree* t, uint64_t* out8) {
         fprintf(stderr, "[bbhip phases, cycles/insert]");
         const double n = (double)(t->h.stats[2] + t->h.stats[3]);
         for (int i = 0; i < 8; ++i) fprintf(stderr, " p%d=%.0f", i, n > 0 ? (double)t->h.phase[i] / n : 0.0);
+        static const char* cls[3] = {"zero-skip", "mirror-hit", "miss"};
+        for (int i = 0; i < 3; ++i)
+            fprintf(stderr, "\n[bbhip descent] %-10s levels/insert=%.3f cycles/level=%.0f", cls[i],
+                    n > 0 ? (double)t->h.phase[11 + i] / n : 0.0,
+                    t->h.phase[11 + i] ? (double)t->h.phase[8 + i] / (double)t->h.phase[11 + i] : 0.0);
         fprintf(stderr, "\n[bbhip split phases, cycles/split]");
         const double ns = (double)t->h.stats[4];
         for (int i = 0; i < 8; ++i) fprintf(stderr, " s%d=%.0f", i, ns > 0 ? (double)t->h.sphase[i] / ns : 0.0);
