@@ -648,7 +648,8 @@ __device__ __forceinline__ Cand node_best_mirror(const KCt& k, int& cmp_par, uin
 #pragma unroll
     for (int i = 0; i < 4; ++i) xv[i] = *(LA u32x4_t*)(k.L + vec_off + wave * 64 + i * 16);
     const uint32_t last = len - 1;  // len >= 1
-    for (uint32_t r0 = 0; r0 < len; r0 += 64) {
+    // loops run over the node's row slots (a compile-time count for KCFix), rows >= len are masked
+    for (uint32_t r0 = 0; r0 < k.rows; r0 += 64) {
         const uint32_t r = r0 + lane;
         const uint32_t rc = r < last ? r : last;
         const uint32_t base = k.o.rc_cent + (mrow0 + rc) * k.RBS + wave * 64;
@@ -665,7 +666,7 @@ __device__ __forceinline__ Cand node_best_mirror(const KCt& k, int& cmp_par, uin
     __syncthreads();
     uint32_t biu = MINMODE ? (0xFFFFu << 16 | 1u) : 1u, br = NONE;  // best of this lane: inter << 16 | union, row
     bool anyc = false;
-    for (uint32_t r0 = 0; r0 < len; r0 += 64) {
+    for (uint32_t r0 = 0; r0 < k.rows; r0 += 64) {
         const uint32_t r = r0 + lane;
         const uint32_t rc = r < last ? r : last;
         uint32_t inter = 0;
@@ -690,12 +691,19 @@ __device__ __forceinline__ Cand node_best_mirror(const KCt& k, int& cmp_par, uin
     }
     BB_STEP(8) BB_STEP(4) BB_STEP(2) BB_STEP(1)
 #undef BB_STEP
-    uint32_t wiu = rdlane(biu, 0), wr = rdlane(br, 0);
-#pragma unroll
-    for (int q = 16; q < 64; q += 16) {
-        const uint32_t ciu = rdlane(biu, q), cr = rdlane(br, q);
-        if (cand_better<MINMODE>(ciu >> 16, ciu & 0xFFFFu, cr, wiu >> 16, wiu & 0xFFFFu, wr)) { wiu = ciu; wr = cr; }
+    // across the four 16-lane rows: row_bcast15 folds rows 0->1 and 2->3, row_bcast31 folds 1->3;
+    // lane 63 then holds the best of the wave
+#define BB_BCAST(CTRL, ROWMASK)                                                                       \
+    {                                                                                                \
+        const uint32_t oiu = (uint32_t)__builtin_amdgcn_update_dpp((int)biu, (int)biu, CTRL, ROWMASK, 0xF, false); \
+        const uint32_t orr = (uint32_t)__builtin_amdgcn_update_dpp((int)br, (int)br, CTRL, ROWMASK, 0xF, false);   \
+        const bool take = cand_better<MINMODE>(oiu >> 16, oiu & 0xFFFFu, orr, biu >> 16, biu & 0xFFFFu, br); \
+        biu = take ? oiu : biu;                                                                      \
+        br = take ? orr : br;                                                                        \
     }
+    BB_BCAST(0x142, 0xA) BB_BCAST(0x143, 0xC)
+#undef BB_BCAST
+    const uint32_t wiu = rdlane(biu, 63), wr = rdlane(br, 63);
     if (out_any_card) *out_any_card = __ballot(anyc) != 0ull;
     Cand best;
     best.i = wiu >> 16;
