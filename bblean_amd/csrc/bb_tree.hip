@@ -1329,6 +1329,7 @@ __device__ __forceinline__ void tree_insert_body(unsigned char* smem_raw, TreeDe
         if (root_hit) root_len = mir_len[0];
         else root_len = uni(ldg<uint32_t>(k.hdr + root));
         Elem el;
+        PHASE(14);
         const long long eidx = SUB ? (long long)uni(gate_elems[g_off + e]) : e;  // position in the input array
         el.idx = eidx;
         // ---- element: packed centroid into LDS, n, moments ------------------------------
@@ -1337,6 +1338,7 @@ __device__ __forceinline__ void tree_insert_body(unsigned char* smem_raw, TreeDe
             if (pf_ok) {
                 // this row was requested while the previous element was being inserted
                 if (tid < k.RBc) sx[tid] = pf;
+                PHASE(15);
                 if (e + 1 < n_elems && tid < k.RBc) {
                     const long long nidx = SUB ? (long long)uni(gate_elems[g_off + e + 1]) : e + 1;
                     pf = ldg<u32x4_t>(in_rows + nidx * row_stride + (size_t)tid * 16);
@@ -1787,6 +1789,7 @@ __global__ __launch_bounds__(TB, 2) void k_tree_insert_dense(TreeDev* trees) {
 
 // shapes with a specialised kernel (KCFix): the benchmark / test default and the CLI default
 using KC50 = KCFix<50, 2048>;
+using KC254 = KCFix<254, 2048>;
 
 // =======================================================================================
 // Batch mode (exact, rollback-free): a prefix of the pending fingerprints is routed through the
@@ -2095,6 +2098,7 @@ int configure(bbh_tree* t, int32_t bf, int32_t n_features) {
         BB_HIP(hipFuncSetAttribute((const void*)k_tree_insert<false, false, KC50>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->lds));
         BB_HIP(hipFuncSetAttribute((const void*)k_tree_insert_dense<KC50>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->lds));
         BB_HIP(hipFuncSetAttribute((const void*)k_tree_insert<true, false, KC50>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->lds));
+        BB_HIP(hipFuncSetAttribute((const void*)k_tree_insert<false, false, KC254>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->lds));
     }
     return BBH_OK;
 }
@@ -2168,10 +2172,11 @@ int run_insert_multi(std::vector<Job>& jobs, hipStream_t s) {
             static const bool prof_phases = getenv("BBHIP_PHASES") != nullptr;
             // trees of the benchmark / default shape run the kernel compiled for that shape
             static const bool no_fix = getenv("BBHIP_NO_FIXED_SHAPE") != nullptr;
-            bool all50 = !no_fix;
-            for (size_t a = 0; a < active.size() && all50; ++a) {
+            bool all50 = !no_fix, all254 = !no_fix;
+            for (size_t a = 0; a < active.size() && (all50 || all254); ++a) {
                 const TreeDev& q = jobs[active[a]].t->h;
-                all50 = q.bf == 50 && q.F == 2048;
+                all50 = all50 && q.bf == 50 && q.F == 2048;
+                all254 = all254 && q.bf == 254 && q.F == 2048;
             }
             if (prof_phases && all50)
                 hipLaunchKernelGGL((k_tree_insert<true, false, KC50>), dim3((unsigned)active.size()), dim3(TB), lds, s, dptr,
@@ -2186,6 +2191,9 @@ int run_insert_multi(std::vector<Job>& jobs, hipStream_t s) {
                 else if (dense) hipLaunchKernelGGL(k_tree_insert_dense<KC>, grid, block, lds, s, dptr);
                 else if (all50)
                     hipLaunchKernelGGL((k_tree_insert<false, false, KC50>), grid, block, lds, s, dptr, (const uint32_t*)nullptr,
+                                       (const uint32_t*)nullptr, (const uint32_t*)nullptr);
+                else if (all254)
+                    hipLaunchKernelGGL((k_tree_insert<false, false, KC254>), grid, block, lds, s, dptr, (const uint32_t*)nullptr,
                                        (const uint32_t*)nullptr, (const uint32_t*)nullptr);
                 else
                     hipLaunchKernelGGL((k_tree_insert<false, false, KC>), grid, block, lds, s, dptr, (const uint32_t*)nullptr,
@@ -2597,6 +2605,8 @@ extern "C" int bbh_tree_stats(bbh_tree* t, uint64_t* out8) {
         const double n = (double)(t->h.stats[2] + t->h.stats[3]);
         for (int i = 0; i < 8; ++i) fprintf(stderr, " p%d=%.0f", i, n > 0 ? (double)t->h.phase[i] / n : 0.0);
         static const char* cls[3] = {"zero-skip", "mirror-hit", "miss"};
+        fprintf(stderr, "\n[bbhip p0 detail] loop-top barrier+checks=%.0f wait-for-prefetched-row=%.0f", n > 0 ? (double)t->h.phase[14] / n : 0.0,
+                n > 0 ? (double)t->h.phase[15] / n : 0.0);
         for (int i = 0; i < 3; ++i)
             fprintf(stderr, "\n[bbhip descent] %-10s levels/insert=%.3f cycles/level=%.0f", cls[i],
                     n > 0 ? (double)t->h.phase[11 + i] / n : 0.0,

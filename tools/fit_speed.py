@@ -1,4 +1,5 @@
-"""Single-tree fit throughput on S-fake rows with the production kernel (no phase timers)."""
+"""Single-tree fit throughput on S-fake rows with the production kernel (no phase timers).
+    python tools/fit_speed.py [n] [reps] [branching_factor] [threshold]"""
 import sys, time
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
 import torch
@@ -6,12 +7,14 @@ from bench import synth_fake_fps
 from bblean_amd import BitBirch
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 200000
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+bf = int(sys.argv[3]) if len(sys.argv) > 3 else 50
+thr = float(sys.argv[4]) if len(sys.argv) > 4 else 0.3
 fps = synth_fake_fps(n, 1000, torch.device("cuda"))
 torch.cuda.synchronize()
 best = None
 for _ in range(reps):
     t0 = time.perf_counter()
-    t = BitBirch(branching_factor=50, threshold=0.3).fit(fps)
+    t = BitBirch(branching_factor=bf, threshold=thr).fit(fps)
     dt = time.perf_counter() - t0
     best = dt if best is None else min(best, dt)
-print(f"{n/best:.0f} fps/s  ({best/n*1e6:.2f} us/insert, best of {reps})", t._engine.stats()[:5])
+print(f"bf={bf} thr={thr}: {n/best:.0f} fps/s  ({best/n*1e6:.2f} us/insert, best of {reps})", t._engine.stats()[:5])
