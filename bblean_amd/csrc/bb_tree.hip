@@ -1382,6 +1382,7 @@ __device__ __forceinline__ void tree_insert_body(unsigned char* smem_raw, TreeDe
             el.s2S = acc[1];
             el.pcx = lds_vec_popcount(k, k.o.x);
         }
+        el.nS = uni(el.nS); el.pcx = uni(el.pcx); el.s1S = uni64(el.s1S); el.s2S = uni64(el.s2S);
         PHASE(0);
 
         uint32_t out_id = NONE;
@@ -1417,6 +1418,8 @@ __device__ __forceinline__ void tree_insert_body(unsigned char* smem_raw, TreeDe
             for (int q = 0; q < MAXFAST; ++q) { tslot[q] = 0; tn[q] = 0; }
             bool bad = false;
             while (true) {
+                depth = (int)uni((uint32_t)depth);  // wave-uniform by construction; stops divergence analysis from
+                nd = uni(nd);                       // treating everything derived from the loop counter as per-lane
                 Cand best;
                 bool hit = false, zero = false, anyc = true;
 #pragma unroll
@@ -1476,6 +1479,10 @@ __device__ __forceinline__ void tree_insert_body(unsigned char* smem_raw, TreeDe
                     rm0 = ldg<u32x4_t>(rmp);
                     rm1 = ldg<u32x4_t>(rmp + 16);
                 }
+                // exit conditions through readfirstlane: a loop whose exit the compiler cannot prove uniform
+                // makes every value that leaves it per-lane (VGPRs, exec-mask branches) downstream
+                leaf = uni(leaf);
+                link = uni(link);
                 if (leaf) break;
                 if (depth + 2 >= MAXD || link >= cap_nodes) { bad = true; break; }  // never spin on corruption
                 nd = link;
@@ -1483,10 +1490,10 @@ __device__ __forceinline__ void tree_insert_body(unsigned char* smem_raw, TreeDe
             }
             if (bad) { stop = STOP_DEPTH; break; }
             PHASE(1);
-            D = depth;
+            D = (int)uni((uint32_t)depth);  // loop-carried: tell the compiler it is wave-uniform
             if (tid == 0 && (u64)(D + 1) > stats[6]) stats[6] = (u64)(D + 1);
-            const uint32_t leafnode = nd, jl = j, leaflen = len;
-            const uint32_t slotT = link;  // leaf row: link = CF slot word
+            const uint32_t leafnode = uni(nd), jl = uni(j), leaflen = uni(len);
+            const uint32_t slotT = uni(link);  // leaf row: link = CF slot word
             const uint32_t Tsub = uni(rm0.x);
             const u64 nT = uni(rm0.y);
             const u64 s1T = ((u64)uni(rm1.y) << 32) | uni(rm1.x);
@@ -1744,6 +1751,7 @@ __device__ __forceinline__ void tree_insert_body(unsigned char* smem_raw, TreeDe
             for (int lv = 0; lv < upd_levels; ++lv) update_tracker_slow(k, el, red_slot, lv, stop);
         }
         PHASE(5);
+        stop = (int)uni((uint32_t)stop);
         if (stop != STOP_DONE) break;
         if (tid == 0 && out_leaf) stg<uint32_t>(out_leaf + eidx, out_id);
     }
