@@ -44,7 +44,8 @@ namespace {
 constexpr int TB = 256;  // threads per tree workgroup
 constexpr int TW = TB / 64;
 constexpr uint32_t NONE = 0xFFFFFFFFu;
-constexpr int MAXD = 64;     // deepest tree handled
+constexpr int MAXD = 256;    // deepest tree handled (the reference recurses: ~990 levels at most; trees this deep only
+                             // arise from degenerate branching factors 2-3)
 constexpr int MAXFAST = 5;   // ancestor levels updated in the fused fast path
 constexpr int NRED = 2 + MAXFAST;
 constexpr int MAX_BF = 1023;
