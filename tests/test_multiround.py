@@ -111,3 +111,23 @@ def test_multiround_distributed_gloo_world2(case):
         on_disk = pickle.load(open(d / "out" / "clusters.pkl", "rb"))
     assert clusters == on_disk
     _check(case, clusters)
+
+
+@pytest.mark.gpu
+def test_multiround_distributed_rccl_world1_hip():
+    r"""The one-process-per-GPU entry point on the real stack: HIP engine + torch.distributed
+    "nccl" (= RCCL) collectives on device tensors.  One rank only (the GPU box has one device;
+    RCCL refuses two ranks on one GPU) - the world-2 exchange logic is covered by the gloo test."""
+    case = MULTIROUND_CASES[0]
+    kwargs = {k: v for k, v in case["kwargs"].items()}
+    with tempfile.TemporaryDirectory() as d:
+        d = Path(d)
+        _write_files(d, case)
+        (d / "out").mkdir()
+        src = _WORKER.format(repo=str(REPO), use_oracle=False, backend="nccl", port=_free_port(), world=1, d=str(d), kwargs=kwargs)
+        (d / "worker.py").write_text(src)
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        p = subprocess.Popen([sys.executable, str(d / "worker.py"), "0"], env=env)
+        assert p.wait(timeout=600) == 0
+        clusters = pickle.load(open(d / "clusters_rank0.pkl", "rb"))
+    _check(case, clusters)
