@@ -118,6 +118,31 @@ def test_hip_concurrent_trees_equal_sequential():
         assert (np.array(together[i].get_centroids()) == np.array(alone.get_centroids())).all()
 
 
+@pytest.mark.parametrize("bf,n_trees", [(50, 300), (20, 280)])
+def test_hip_many_trees_two_workgroups_per_cu(bf, n_trees):
+    r"""More trees than compute units: the launch switches to the two-workgroups-per-CU kernel
+    (shape-specialised for bf 50, generic otherwise).  Every tree must equal the oracle's."""
+    from bblean_amd import fit_concurrently
+
+    pool = make_fake_fingerprints(12_000, seed=31)
+    rng = np.random.default_rng(8)
+    shards, ids = [], []
+    start = 0
+    for i in range(n_trees):
+        m = int(rng.integers(150, 900))
+        shards.append(pool[rng.integers(0, len(pool), m)])
+        ids.append(range(start, start + m))
+        start += m
+    together = [BitBirch(branching_factor=bf, threshold=0.3) for _ in shards]
+    fit_concurrently(together, shards, reinsert_indices=ids)
+    for i in (0, 1, 57, 128, 199, 255, 256, 257, n_trees - 1):
+        ora = BitBirch(branching_factor=bf, threshold=0.3, _engine_factory=OracleEngine).fit(shards[i], reinsert_indices=ids[i])
+        assert together[i].get_cluster_mol_ids() == ora.get_cluster_mol_ids()  # global ids: no get_assignments
+        assert (np.array(together[i].get_centroids()) == np.array(ora.get_centroids())).all()
+        assert together[i]._engine.stats()[:7].tolist() == ora._engine.stats()[:7].tolist()
+    assert [sum(len(c) for c in t.get_cluster_mol_ids()) for t in together] == [len(s) for s in shards]
+
+
 def test_hip_tree_full_size_1M_vs_oracle():
     r"""BASELINE.json configs[1] at full size: 1 M synthetic 2048-bit fingerprints, thr 0.3,
     bf 50 - cluster ids of the HIP engine must equal the CPU oracle's, element by element."""
