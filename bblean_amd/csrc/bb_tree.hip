@@ -2010,13 +2010,21 @@ int grow_nodes(bbh_tree* t, uint32_t want) {
     TreeDev& h = t->h;
     if (want <= h.cap_nodes) return BBH_OK;
     const size_t rows = (size_t)h.bf + 1;
-    const size_t oc = std::min<size_t>(h.cap_nodes, h.ctr[C_NODES]), nc = want;  // live nodes only
+    // a tree that has not received anything yet owns one empty root: nothing to carry over but its
+    // 16-byte header (a multiround round creates hundreds of trees and grows each of them once)
+    const bool pristine = h.cap_nodes > 0 && h.ctr[C_NODES] == 1 && h.ctr[C_IDS] == 0 && h.stats[3] == 0;
+    const size_t oc = pristine ? 0 : std::min<size_t>(h.cap_nodes, h.ctr[C_NODES]), nc = want;  // live nodes only
     BB_TRY(grow_pool(h.node_cent, oc * rows * h.RB, nc * rows * h.RB));
     BB_TRY(grow_pool(h.node_card, oc * rows, nc * rows));
     BB_TRY(grow_pool(h.node_link, oc * rows, nc * rows));
     BB_TRY(grow_pool(h.node_rm, oc * rows, nc * rows));
     BB_TRY(grow_pool(h.node_hdr, oc, nc));
     h.cap_nodes = (uint32_t)nc;
+    if (pristine) {
+        NodeHdr root;
+        root.len = 0; root.leaf = 1; root.prev = NONE; root.next = NONE;
+        BB_HIP(hipMemcpy(h.node_hdr, &root, sizeof(root), hipMemcpyHostToDevice));
+    }
     return BBH_OK;
 }
 
