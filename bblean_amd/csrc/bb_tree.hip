@@ -1495,6 +1495,20 @@ __device__ __forceinline__ void tree_insert_body(unsigned char* smem_raw, TreeDe
             if (tid == 0 && (u64)(D + 1) > stats[6]) stats[6] = (u64)(D + 1);
             const uint32_t leafnode = uni(nd), jl = uni(j), leaflen = uni(len);
             const uint32_t slotT = uni(link);  // leaf row: link = CF slot word
+            // Request the cluster features of the chosen leaf row and of every ancestor NOW, before the
+            // leaf row's RowMeta (still in flight) is looked at: one memory round trip instead of two.
+            const bool fast = nb <= TB;  // one byte-group (8 features) per thread
+            const int b0 = tid;
+            const bool act = fast && b0 < nb;
+            const int DT = D < MAXFAST ? D : MAXFAST;  // ancestors handled in the fused pass
+            u32x4_t rawL[2] = {(u32x4_t)(0), (u32x4_t)(0)};
+            uint32_t vT[MAXFAST][8];
+            if (act) {
+                cf_load_raw(k, slotT, b0, rawL);
+#pragma unroll
+                for (int q = 0; q < MAXFAST; ++q)
+                    if (q < DT) cf32_load8(k, tslot[q], b0, vT[q]);
+            }
             const uint32_t Tsub = uni(rm0.x);
             const u64 nT = uni(rm0.y);
             const u64 s1T = ((u64)uni(rm1.y) << 32) | uni(rm1.x);
@@ -1503,26 +1517,17 @@ __device__ __forceinline__ void tree_insert_body(unsigned char* smem_raw, TreeDe
             if (new_n > 0xFFFFFFFFull) { stop = STOP_RANGE; break; }
             // ---- one fused pass: leaf dot product, speculative merged CF + centroid, and
             //      every ancestor's CF += element with its new centroid; one reduction ----
-            const bool fast = nb <= TB;  // one byte-group (8 features) per thread
             u64 dot = 0;
             uint32_t pcs[1 + MAXFAST];  // [0] merged leaf centroid popcount, [1+q] ancestor q's
 #pragma unroll
             for (int i = 0; i < 1 + MAXFAST; ++i) pcs[i] = 0;
-            uint32_t xs[8], vL[8], vT[MAXFAST][8], byteL = 0, byteT[MAXFAST];
-            const int b0 = tid;
-            const bool act = fast && b0 < nb;
-            const int DT = D < MAXFAST ? D : MAXFAST;  // ancestors handled here
+            uint32_t xs[8], vL[8], byteL = 0, byteT[MAXFAST];
             const bool wide_dot = bufmode || (slotT >> 30) == 2;
 #pragma unroll
             for (int q = 0; q < MAXFAST; ++q) byteT[q] = 0;
             if (fast) {
                 if (act) {
                     elem_cols(k, el, b0, xs);
-                    u32x4_t rawL[2];
-                    cf_load_raw(k, slotT, b0, rawL);  // leaf and ancestor CFs travel together
-#pragma unroll
-                    for (int q = 0; q < MAXFAST; ++q)
-                        if (q < DT) cf32_load8(k, tslot[q], b0, vT[q]);
                     cf_unpack_raw(slotT >> 30, rawL, vL);
                     if (wide_dot) {
 #pragma unroll
