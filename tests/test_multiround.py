@@ -131,3 +131,24 @@ def test_multiround_distributed_rccl_world1_hip():
         assert p.wait(timeout=600) == 0
         clusters = pickle.load(open(d / "clusters_rank0.pkl", "rb"))
     _check(case, clusters)
+
+
+@pytest.mark.gpu
+def test_multiround_distributed_two_ranks_hip_engine():
+    r"""Two ranks with the HIP engine (both on the one GPU of the box; the exchange runs over gloo
+    because RCCL refuses two ranks per device): the rank-sharded rounds must give the reference's
+    clusters.  Together with the one-rank RCCL test this covers both halves of the N-GPU path."""
+    case = MULTIROUND_CASES[1]
+    kwargs = {k: v for k, v in case["kwargs"].items()}
+    with tempfile.TemporaryDirectory() as d:
+        d = Path(d)
+        _write_files(d, case)
+        (d / "out").mkdir()
+        src = _WORKER.format(repo=str(REPO), use_oracle=False, backend="gloo", port=_free_port(), world=2, d=str(d), kwargs=kwargs)
+        (d / "worker.py").write_text(src)
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs = [subprocess.Popen([sys.executable, str(d / "worker.py"), str(r)], env=env) for r in range(2)]
+        for p in procs:
+            assert p.wait(timeout=600) == 0
+        clusters = pickle.load(open(d / "clusters_rank0.pkl", "rb"))
+    _check(case, clusters)
