@@ -174,11 +174,11 @@ __host__ __device__ constexpr Smem smem_layout(int bf, int RB, int nm) {
 }
 
 // mirrored path levels for a (branching factor, row bytes) pair: as many (<= MAXM) as keep the
-// workgroup's LDS under 100 KiB; only 2048-bit rows are mirrored
+// workgroup inside the CU's 160 KiB of LDS; only 2048-bit rows are mirrored
 __host__ __device__ constexpr int mirror_levels(int bf, int RB) {
     if (RB != 256) return 0;
     for (int q = MAXM; q >= 1; --q)
-        if (smem_layout(bf, RB, q).total <= 100 * 1024) return q;
+        if (smem_layout(bf, RB, q).total <= 160 * 1024) return q;
     return 0;
 }
 
