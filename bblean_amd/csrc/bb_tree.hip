@@ -20,16 +20,24 @@
 //               internal nodes always live in cf32.
 //
 // Execution model: one 256-thread workgroup per tree inserts a whole batch with the
-// reference's sequential semantics.  Inside an insert the work is data parallel: 16 lanes
-// x 16 B cover a 256-byte centroid row (16 rows per pass, DPP row reduction of the
-// AND-popcounts), per-row keys meet in LDS, the cluster-feature update is one thread per 8
-// features, and the leaf test + every ancestor's CF update share one block reduction.  The
-// root node is mirrored in LDS.  Everything wave-uniform (node ids, rows, lengths, slots)
-// is kept in SGPRs (readfirstlane / readlane), every pool access is an explicit
-// global-address-space access and every scratchpad access an LDS access, so the compiler
-// emits scalar control flow, global_load/ds_read and no private-memory traffic.
+// reference's sequential semantics.  Inside an insert the work is data parallel.  Nodes read
+// from HBM: 16 lanes x 16 B cover a 256-byte centroid row (16 rows per pass, DPP row reduction
+// of the AND-popcounts).  The nodes of the most recent root-to-leaf path are mirrored in LDS
+// (as many levels as fit in the CU's 160 KiB) and compared one row per lane, a quarter of the
+// row per wave (node_best_mirror).  The cluster-feature update is one thread per 8 features,
+// and the leaf test + every ancestor's CF update share one block reduction.  Everything
+// wave-uniform (node ids, rows, lengths, slots) is kept in SGPRs (readfirstlane / readlane),
+// every pool access is an explicit global-address-space access and every scratchpad access an
+// LDS access, so the compiler emits scalar control flow, global_load/ds_read and no
+// private-memory traffic.  The device code is templated on a context type: KC carries the
+// tree's shape as run-time values, KCFix<BF, NF> as compile-time constants (instantiated for
+// the benchmark shape 50 x 2048 bits and the CLI default 254 x 2048).
 // All decisions use exact integers; the only floating point is the reference's own f64
 // formulae in the same operation order.
+//
+// Also here: the exact batch mode for one tree (k_route / k_upd + bb_tree_batch.inc, DESIGN.md
+// section 6b), many independent trees per launch (one or two workgroups per CU), the streaming
+// ingest of host / file-backed rows (HostSlabs) and the leaf export kernels.
 #include "bb_common.h"
 
 #include <algorithm>
