@@ -130,6 +130,30 @@ class HipEngine:
         _lib.check(lib.bbh_trees_fit_packed(handles, k, rows_p, n_p, s_p, out_p, None))
         return outs
 
+    @staticmethod
+    def fit_buffers_many(engines: "list[HipEngine]", bufs_list: list) -> list[NDArray[np.uint32]]:
+        r"""`fit_buffers` for several trees with ONE kernel launch (one workgroup per tree)."""
+        lib = _lib.load()
+        k = len(engines)
+        keep, ks, widths, outs = [], [], [], []
+        for eng, bufs in zip(engines, bufs_list):
+            b = np.ascontiguousarray(bufs)
+            if b.ndim != 2 or b.shape[1] != eng.n_features + 1:
+                raise RuntimeError("buffers must have shape (k, n_features + 1)")
+            if b.dtype.kind != "u":
+                b = b.astype(np.uint64)
+            keep.append(b)
+            ks.append(b.shape[0])
+            widths.append(b.dtype.itemsize)
+            outs.append(np.empty(b.shape[0], dtype=np.uint32))
+        handles = (C.c_void_p * k)(*[e._h for e in engines])
+        bufs_p = (C.c_void_p * k)(*[b.ctypes.data if b.size else None for b in keep])
+        w_p = (C.c_int32 * k)(*widths)
+        k_p = (C.c_int64 * k)(*ks)
+        out_p = (C.c_void_p * k)(*[o.ctypes.data if o.size else None for o in outs])
+        _lib.check(lib.bbh_trees_fit_buffers(handles, k, bufs_p, w_p, k_p, out_p, None))
+        return outs
+
     def fit_buffers(self, bufs: NDArray[np.integer], stream: int | None = None) -> NDArray[np.uint32]:
         r"""Insert BitFeature buffers, shape (k, n_features + 1), unsigned dtype."""
         bufs = np.ascontiguousarray(bufs)

@@ -53,6 +53,7 @@ _PROTOTYPES = {
     "bbh_tree_fit_packed": (_int, [_vp, _vp, _i64, _i64, _vp, _vp]),
     "bbh_tree_fit_buffers": (_int, [_vp, _vp, _i32, _i64, _vp, _vp]),
     "bbh_trees_fit_packed": (_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "bbh_trees_fit_buffers": (_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp]),
     "bbh_tree_leaf_count": (_int, [_vp, C.POINTER(_i64)]),
     "bbh_tree_export_leaves": (_int, [_vp, _vp, _vp, _vp, _vp, _i32]),
     "bbh_tree_gather_buffers": (_int, [_vp, _vp, _i64, _i32, _vp]),

@@ -385,6 +385,15 @@ class BitBirch:
     ) -> "BitBirch":
         r"""Insert BitFeature buffers ``[linear_sum | n_samples]`` in order
         (reference bitbirch.py:790-866)."""
+        prepared = self._prepare_fit_buffers(X, reinsert_index_seqs)
+        if prepared is not None:
+            bufs, counts, flat = prepared
+            self._commit_fit_buffers(self._engine.fit_buffers(bufs), counts, flat)
+        return self
+
+    def _prepare_fit_buffers(self, X, reinsert_index_seqs):  # type: ignore[no-untyped-def]
+        r"""Everything `_fit_buffers` does before the hot loop.  Returns (buffers, member counts, member
+        ids) or None when there is nothing to insert."""
         if isinstance(X, (Path, str)):
             X = np.load(Path(X), mmap_mode="r")
         nf = _validate_n_features(X, input_is_packed=False) - 1
@@ -421,14 +430,16 @@ class BitBirch:
                     f" but found {int(counts[i])} != {int(bufs[i, -1])}"
                 )
         self._is_init = True
-        if k:
-            leaf = self._engine.fit_buffers(bufs)
-            self._log_leaf.append(leaf)
-            self._log_counts.append(counts.astype(np.int64))
-            self._log_ids.append(flat.astype(np.int64))
-            self._num_fitted_fps += int(counts.sum())
-            self._cache.clear()
-        return self
+        if not k:
+            return None
+        return bufs, counts, flat
+
+    def _commit_fit_buffers(self, leaf: NDArray[np.uint32], counts: NDArray, flat: NDArray) -> None:
+        self._log_leaf.append(leaf)
+        self._log_counts.append(counts.astype(np.int64))
+        self._log_ids.append(flat.astype(np.int64))
+        self._num_fitted_fps += int(counts.sum())
+        self._cache.clear()
 
     # ----------------------------------------------------------- tree lifecycle ----
     def reset(self) -> None:
@@ -864,6 +875,38 @@ def fit_concurrently(
     for t, leaf, (_, ids) in zip(trees, leaves, prepared):
         if len(ids):
             t._commit_fit(leaf, ids)
+
+
+def fit_buffers_concurrently(
+    trees: tp.Sequence[BitBirch],
+    tables: tp.Sequence[tp.Sequence[tuple[tp.Any, tp.Any]]],
+) -> None:
+    r"""`tree._fit_buffers(bufs, idx)` for every ``(bufs, idx)`` of ``tables[i]``, in order, for
+    several independent trees at once: the trees of one multiround merge round (reference
+    multiround.py:240-264, one process per tree there).  Step s inserts the s-th table of every
+    tree that has one in ONE kernel launch (one workgroup per tree); results are identical to
+    looping over the trees."""
+    if len(trees) != len(tables):
+        raise ValueError("need one table list per tree")
+    steps = max((len(t) for t in tables), default=0)
+    for s in range(steps):
+        live, prepared = [], []
+        for tree, tabs in zip(trees, tables):
+            if s < len(tabs):
+                prep = tree._prepare_fit_buffers(tabs[s][0], tabs[s][1])
+                if prep is not None:
+                    live.append(tree)
+                    prepared.append(prep)
+        if not live:
+            continue
+        engines = [t._engine for t in live]
+        many = getattr(type(engines[0]), "fit_buffers_many", None)
+        if many is not None and all(type(e) is type(engines[0]) for e in engines):
+            leaves = many(engines, [p[0] for p in prepared])
+        else:
+            leaves = [e.fit_buffers(p[0]) for e, p in zip(engines, prepared)]
+        for tree, leaf, (_, counts, flat) in zip(live, leaves, prepared):
+            tree._commit_fit_buffers(leaf, counts, flat)
 
 
 def _rows_from_file_seq(files: tp.Sequence[Path], idxs: NDArray[np.int64]) -> NDArray[np.uint8]:

@@ -2555,6 +2555,40 @@ extern "C" int bbh_trees_fit_packed(bbh_tree** trees, int32_t n_trees, const uin
     return BBH_OK;
 }
 
+// The same for BitFeature buffers: the trees of one merge round (reference multiround.py:240-264
+// builds them one process each), each inserting its own table in one shared launch.
+extern "C" int bbh_trees_fit_buffers(bbh_tree** trees, int32_t n_trees, const void* const* bufs, const int32_t* width,
+                                     const int64_t* k, uint32_t* const* out_leaf, void* stream) {
+    if (!trees || n_trees < 0 || !bufs || !width || !k) return bb::fail(BBH_ERR_INVALID, "null argument");
+    if (n_trees == 0) return BBH_OK;
+    hipStream_t s = (hipStream_t)stream;
+    std::vector<Job> jobs;
+    std::vector<bb::DevIn> ins((size_t)n_trees);
+    std::vector<bb::DevOut> outs((size_t)n_trees);
+    const int device = trees[0]->device;
+    BB_HIP(hipSetDevice(device));
+    for (int32_t i = 0; i < n_trees; ++i) {
+        bbh_tree* t = trees[i];
+        if (!t || t->device != device) return bb::fail(BBH_ERR_INVALID, "all trees of one call must live on one device");
+        const int w = width[i];
+        if (w != 1 && w != 2 && w != 4 && w != 8) return bb::fail(BBH_ERR_INVALID, "buffer element width must be 1, 2, 4 or 8");
+        if (k[i] < 0) return bb::fail(BBH_ERR_INVALID, "negative buffer count");
+        if (k[i] == 0) continue;
+        if (w == 1) BB_TRY(grow_cf(t, 0, clamp30((uint64_t)t->h.ctr[C_N8] + (uint64_t)k[i] + 64)));
+        if (w == 2) BB_TRY(grow_cf(t, 1, clamp30((uint64_t)t->h.ctr[C_N16] + (uint64_t)k[i] + 64)));
+        BB_TRY(grow_nodes(t, clamp30((uint64_t)t->h.ctr[C_NODES] + (uint64_t)k[i] / std::max(1, t->h.bf / 3) + 64)));
+        BB_TRY(grow_cf(t, 2, clamp30((uint64_t)t->h.ctr[C_N32] + (uint64_t)k[i] / std::max(1, t->h.bf / 6) + 256)));
+        const size_t row_bytes = ((size_t)t->h.F + 1) * (size_t)w;
+        BB_TRY(ins[(size_t)i].init(bufs[i], (size_t)k[i] * row_bytes, s));
+        BB_TRY(outs[(size_t)i].init(out_leaf ? out_leaf[i] : nullptr, (size_t)k[i] * 4));
+        jobs.push_back(Job{t, nullptr, 0, (const uint8_t*)ins[(size_t)i].dev, w, k[i], (uint32_t*)outs[(size_t)i].dev, 0, 0});
+    }
+    BB_TRY(run_insert_multi(jobs, s));
+    for (auto& o : outs) BB_TRY(o.finish(s));
+    BB_HIP(hipStreamSynchronize(s));
+    return BBH_OK;
+}
+
 extern "C" int bbh_tree_leaf_count(bbh_tree* t, int64_t* out) {
     if (!t || !out) return bb::fail(BBH_ERR_INVALID, "null argument");
     BB_HIP(hipSetDevice(t->device));

@@ -6,7 +6,9 @@ Two front ends over the same round logic:
   (`multiround.py:333-484`): shard s = input file s, round 1 fits every shard (+ optional
   refinement), later rounds re-insert the leaf BitFeature tables batch by batch, exchanging
   `round-{r}-bufs.label-{L}-uint{08,16,..}.npy` / `round-{r}-idxs....pkl` files
-  (`multiround.py:132-143`).  One process, one GPU: the shards run back to back on the device.
+  (`multiround.py:132-143`).  One process, one GPU: the shards of round 1 and the batches of a merge
+  round run CONCURRENTLY on the device, one workgroup per tree in shared kernel launches
+  (`fit_concurrently` / `fit_buffers_concurrently`), where the reference uses a process pool.
 
 * `run_multiround_distributed` - one process per GPU (`torch.distributed`, backend "nccl" =
   RCCL over xGMI; "gloo" in the CPU tests).  Round 1 is embarrassingly parallel (rank r owns
@@ -27,7 +29,7 @@ from pathlib import Path
 import numpy as np
 from numpy.typing import NDArray
 
-from bblean_amd.bitbirch import BitBirch, _IndexLists
+from bblean_amd.bitbirch import BitBirch, _IndexLists, fit_buffers_concurrently, fit_concurrently
 from bblean_amd.utils import batched
 
 __all__ = ["run_multiround_bitbirch", "run_multiround_distributed"]
@@ -78,46 +80,71 @@ def _files_range_tuples(files: tp.Sequence[Path]) -> list[tuple[str, Path, int, 
 Tables = tuple[dict[str, NDArray[np.integer]], dict[str, _IndexLists]]
 
 
-def _initial_round(
-    info: tuple[str, Path, int, int], *, branching_factor: int, threshold: float, tolerance: float,
+# host/device bytes of raw input handed to one concurrent launch group
+_GROUP_BYTES = 24 << 30
+
+
+def _groups(sizes: tp.Sequence[int], limit: int = _GROUP_BYTES, max_trees: int = 2048) -> list[range]:
+    r"""Consecutive index ranges whose inputs stay under `limit` bytes (at least one per group)."""
+    out, lo, acc = [], 0, 0
+    for i, sz in enumerate(sizes):
+        if i > lo and (acc + sz > limit or i - lo >= max_trees):
+            out.append(range(lo, i))
+            lo, acc = i, 0
+        acc += sz
+    if lo < len(sizes):
+        out.append(range(lo, len(sizes)))
+    return out
+
+
+def _initial_rounds(
+    infos: tp.Sequence[tuple[str, Path, int, int]], *, branching_factor: int, threshold: float, tolerance: float,
     merge_criterion: str, refinement: str, refine_merge_criterion: str, refine_threshold_change: float,
     n_features: int | None, input_is_packed: bool, max_fps: int | None, engine_factory: tp.Any, device: int,
-) -> Tables:
-    r"""`_InitialRound.__call__` (multiround.py:175-216) returning tables instead of files."""
-    _, fp_file, start, end = info
-    tree = BitBirch(branching_factor=branching_factor, threshold=threshold, merge_criterion=merge_criterion,
-                    device=device, _engine_factory=engine_factory)
-    tree.fit(fp_file, reinsert_indices=range(start, end), n_features=n_features,
-             input_is_packed=input_is_packed, max_fps=max_fps)
-    tree.delete_internal_nodes()
-    if refinement == "none":
-        bufs, mols = tree._bf_tables(tree._leaf_order(True))
-    else:
-        bufs, mols = tree._refine_tables(fp_file, initial_mol=start, input_is_packed=input_is_packed)
+) -> list[Tables]:
+    r"""`_InitialRound.__call__` (multiround.py:175-216) for several shards at once, returning tables
+    instead of files.  Every step that touches the device runs for all shards of a group in one
+    launch; the per-shard results are those of the reference's one-process-per-shard pool."""
+    out: list[Tables] = []
+    sizes = [max(int(Path(f).stat().st_size), 1) for _, f, _, _ in infos]
+    for grp in _groups(sizes):
+        part = [infos[i] for i in grp]
+        trees = [BitBirch(branching_factor=branching_factor, threshold=threshold, merge_criterion=merge_criterion,
+                          device=device, _engine_factory=engine_factory) for _ in part]
+        fit_concurrently(trees, [f for _, f, _, _ in part], reinsert_indices=[range(s, e) for _, _, s, e in part],
+                         input_is_packed=input_is_packed, n_features=n_features, max_fps=max_fps)
+        for t in trees:
+            t.delete_internal_nodes()
+        if refinement == "none":
+            out.extend(t._bf_tables(t._leaf_order(True)) for t in trees)
+            continue
+        tabs = [t._refine_tables(f, initial_mol=s, input_is_packed=input_is_packed) for t, (_, f, s, _) in zip(trees, part)]
         if refinement == "full":
-            tree.reset()
-            tree.set_merge(refine_merge_criterion, tolerance=tolerance,
-                           threshold=threshold + refine_threshold_change)
-            for name in bufs:
-                tree._fit_buffers(bufs[name], reinsert_index_seqs=mols[name])
-            tree.delete_internal_nodes()
-            bufs, mols = tree._bf_tables(tree._leaf_order(True))
-    return bufs, mols
+            for t in trees:
+                t.reset()
+                t.set_merge(refine_merge_criterion, tolerance=tolerance, threshold=threshold + refine_threshold_change)
+            fit_buffers_concurrently(trees, [[(bufs[name], mols[name]) for name in bufs] for bufs, mols in tabs])
+            for t in trees:
+                t.delete_internal_nodes()
+            tabs = [t._bf_tables(t._leaf_order(True)) for t in trees]
+        out.extend(tabs)
+    return out
 
 
-def _merge_round(
-    pairs: tp.Sequence[tuple[NDArray[np.integer], _IndexLists]], *, branching_factor: int, threshold: float,
+def _merge_rounds(
+    batches: tp.Sequence[tp.Sequence[tuple[NDArray[np.integer], _IndexLists]]], *, branching_factor: int, threshold: float,
     tolerance: float, criterion: str, engine_factory: tp.Any, device: int,
-    split_largest: bool = False, all_fp_paths: tp.Sequence[Path] = (),
-) -> BitBirch:
-    r"""`_TreeMergingRound.__call__` (multiround.py:240-264): rebuild one tree from the
-    BitFeature tables of a batch, in the given order."""
-    tree = BitBirch(branching_factor=branching_factor, threshold=threshold, merge_criterion=criterion,
-                    tolerance=tolerance, device=device, _engine_factory=engine_factory)
-    for bufs, idx in pairs:
-        tree._fit_buffers(bufs, reinsert_index_seqs=idx)
-    tree.delete_internal_nodes()
-    return tree
+) -> list[BitBirch]:
+    r"""`_TreeMergingRound.__call__` (multiround.py:240-264) for several batches at once: one tree per
+    batch, rebuilt from the batch's BitFeature tables in the given order, all trees in shared launches."""
+    trees = [BitBirch(branching_factor=branching_factor, threshold=threshold, merge_criterion=criterion,
+                      tolerance=tolerance, device=device, _engine_factory=engine_factory) for _ in batches]
+    sizes = [sum(int(np.asarray(b).nbytes) for b, _ in batch) + 1 for batch in batches]
+    for grp in _groups(sizes):
+        fit_buffers_concurrently([trees[i] for i in grp], [list(batches[i]) for i in grp])
+    for t in trees:
+        t.delete_internal_nodes()
+    return trees
 
 
 def _save_tables(out_dir: Path, bufs: dict, mols: dict, label: str, round_idx: int) -> None:
@@ -166,7 +193,7 @@ def run_multiround_bitbirch(
 ) -> _Timer:
     r"""File-compatible multiround on one GPU.  The process-count arguments are accepted for
     signature compatibility; the result never depended on them (tests/test_multiround.py of the
-    reference asserts that) and the shards simply run back to back on the device."""
+    reference asserts that); shards and batches share kernel launches on the device instead."""
     if refinement_before_midsection not in ("full", "split", "none"):
         raise ValueError(f"Unknown refinement kind {refinement_before_midsection}")
     if num_midsection_processes is not None and num_midsection_processes > num_initial_processes:
@@ -181,12 +208,12 @@ def run_multiround_bitbirch(
 
     round_idx = 1
     timer.init_timing(f"round-{round_idx}")
-    for info in _files_range_tuples(input_files):
-        bufs, mols = _initial_round(
-            info, threshold=threshold, merge_criterion=initial_merge_criterion,
+    infos = _files_range_tuples(input_files)
+    for info, (bufs, mols) in zip(infos, _initial_rounds(
+            infos, threshold=threshold, merge_criterion=initial_merge_criterion,
             refinement=refinement_before_midsection, refine_merge_criterion=midsection_merge_criterion,
             refine_threshold_change=midsection_threshold_change, n_features=n_features,
-            input_is_packed=input_is_packed, max_fps=max_fps, **common)
+            input_is_packed=input_is_packed, max_fps=max_fps, **common)):
         _save_tables(out_dir, bufs, mols, info[0], 1)
     timer.end_timing(f"round-{round_idx}")
 
@@ -199,10 +226,12 @@ def run_multiround_bitbirch(
         timer.init_timing(f"round-{round_idx}")
         pairs = prev_pairs(round_idx)
         z = len(str(math.ceil(len(pairs) / bin_size)))
-        for i, batch in enumerate(batched(pairs, bin_size)):
-            batch = sorted(batch, key=lambda p: _bits_of(p[0].name), reverse=True)  # multiround.py:104-111
-            tree = _merge_round([_load_pair(*p) for p in batch], threshold=threshold + midsection_threshold_change,
-                                criterion=midsection_merge_criterion, **common)
+        batches = [sorted(batch, key=lambda p: _bits_of(p[0].name), reverse=True)  # multiround.py:104-111
+                   for batch in batched(pairs, bin_size)]
+        trees = _merge_rounds([[_load_pair(*p) for p in batch] for batch in batches],
+                              threshold=threshold + midsection_threshold_change,
+                              criterion=midsection_merge_criterion, **common)
+        for i, tree in enumerate(trees):
             if split_largest_after_each_midsection_round:
                 bufs, mols = tree._refine_tables(input_files)
             else:
@@ -212,8 +241,8 @@ def run_multiround_bitbirch(
 
     round_idx += 1
     timer.init_timing(f"round-{round_idx}")
-    tree = _merge_round([_load_pair(*p) for p in prev_pairs(round_idx)],
-                        threshold=threshold + midsection_threshold_change, criterion=final_merge_criterion, **common)
+    tree = _merge_rounds([[_load_pair(*p) for p in prev_pairs(round_idx)]],
+                         threshold=threshold + midsection_threshold_change, criterion=final_merge_criterion, **common)[0]
     if save_tree:
         raise NotImplementedError("whole-tree pickling is not provided (the reference's --save-tree is broken too)")
     _write_outputs(out_dir, tree, save_centroids)
@@ -330,14 +359,12 @@ def run_multiround_distributed(
     timer.init_timing("round-1")
     infos = _files_range_tuples([Path(f) for f in input_files])
     mine = []
-    for i, info in enumerate(infos):
-        if i % world != rank:
-            continue
-        bufs, mols = _initial_round(
-            info, threshold=threshold, merge_criterion=initial_merge_criterion,
+    my_infos = [info for i, info in enumerate(infos) if i % world == rank]
+    for info, (bufs, mols) in zip(my_infos, _initial_rounds(
+            my_infos, threshold=threshold, merge_criterion=initial_merge_criterion,
             refinement=refinement_before_midsection, refine_merge_criterion=midsection_merge_criterion,
             refine_threshold_change=midsection_threshold_change, n_features=n_features,
-            input_is_packed=input_is_packed, max_fps=max_fps, **common)
+            input_is_packed=input_is_packed, max_fps=max_fps, **common)):
         for name in bufs:
             mine.append((info[0], name, bufs[name], mols[name]))
     timer.end_timing("round-1")
@@ -353,12 +380,12 @@ def run_multiround_distributed(
         everything = ordered(_allgather_tables(mine, dist, tdev))
         z = len(str(math.ceil(len(everything) / bin_size)))
         mine = []
-        for b, batch in enumerate(batched(everything, bin_size)):
-            if b % world != rank:
-                continue
-            batch = sorted(batch, key=lambda e: _CODE[e[1]], reverse=True)  # uint16 tables first
-            tree = _merge_round([(t, idx) for _, _, t, idx in batch], threshold=threshold + midsection_threshold_change,
-                                criterion=midsection_merge_criterion, **common)
+        my_batches = [(b, sorted(batch, key=lambda e: _CODE[e[1]], reverse=True))  # uint16 tables first
+                      for b, batch in enumerate(batched(everything, bin_size)) if b % world == rank]
+        trees = _merge_rounds([[(t, idx) for _, _, t, idx in batch] for _, batch in my_batches],
+                              threshold=threshold + midsection_threshold_change,
+                              criterion=midsection_merge_criterion, **common)
+        for (b, _), tree in zip(my_batches, trees):
             bufs, mols = tree._bf_tables(tree._leaf_order(True))
             for name in bufs:
                 mine.append((str(b).zfill(z), name, bufs[name], mols[name]))
@@ -369,8 +396,8 @@ def run_multiround_distributed(
     everything = ordered(_allgather_tables(mine, dist, tdev))
     clusters = None
     if rank == 0:
-        tree = _merge_round([(t, idx) for _, _, t, idx in everything], threshold=threshold + midsection_threshold_change,
-                            criterion=final_merge_criterion, **common)
+        tree = _merge_rounds([[(t, idx) for _, _, t, idx in everything]], threshold=threshold + midsection_threshold_change,
+                             criterion=final_merge_criterion, **common)[0]
         clusters = tree.get_cluster_mol_ids()
         if out_dir is not None:
             _write_outputs(Path(out_dir), tree, save_centroids)

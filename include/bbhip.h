@@ -154,6 +154,11 @@ int bbh_tree_fit_packed(bbh_tree* t, const uint8_t* rows, int64_t n, int64_t row
 int bbh_trees_fit_packed(bbh_tree** trees, int32_t n_trees, const uint8_t* const* rows,
                          const int64_t* n, const int64_t* row_stride, uint32_t* const* out_leaf,
                          void* stream);
+/* _fit_buffers for several independent trees in one launch (the trees of a merge round,
+ * multiround.py:240-264): tree i inserts k[i] buffers of element width width[i] from bufs[i]. */
+int bbh_trees_fit_buffers(bbh_tree** trees, int32_t n_trees, const void* const* bufs,
+                          const int32_t* width, const int64_t* k, uint32_t* const* out_leaf,
+                          void* stream);
 
 /* BitBirch._fit_buffers hot loop (bitbirch.py:848-866): insert k BitFeature buffers
  * [linear_sum(n_features) | n_samples], elements of `width` bytes (1,2,4,8), row-major
