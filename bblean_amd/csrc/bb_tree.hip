@@ -2428,12 +2428,17 @@ struct HostSlabs {
         if (first >= total) return;
         const int b = (int)((first / per) & 1);
         const int64_t m = std::min(per, total - first);
-        pending = std::async(std::launch::async, [this, b, first, m]() -> int {
+        auto job = [this, b, first, m]() -> int {
             if (hipSetDevice(device) != hipSuccess) return 1;
             std::memcpy(pin[b], src + (size_t)first * unit, (size_t)m * unit);  // page-in happens here
             if (hipMemcpyAsync(dev[b], pin[b], (size_t)m * unit, hipMemcpyHostToDevice, cs) != hipSuccess) return 2;
             return hipStreamSynchronize(cs) == hipSuccess ? 0 : 3;
-        });
+        };
+        try {
+            pending = std::async(std::launch::async, job);
+        } catch (...) {  // no thread to be had: do the transfer inline, nothing may escape the C ABI
+            pending = std::async(std::launch::deferred, job);
+        }
     }
     // rows [first, first + *m) are resident at the returned device pointer; the following slab
     // is already on its way when this returns
