@@ -412,14 +412,27 @@ __device__ __forceinline__ void elem_cols(const KCt& k, const Elem& el, int b, u
         for (int q = 0; q < 8; ++q) v[q] = (xb >> (7 - q)) & 1u;
         return;
     }
+    // BitFeature buffer row: F + 1 values of `width` bytes, so rows are not aligned to anything;
+    // gfx950 under HSA serves unaligned vector loads, one request per thread instead of eight
     const size_t base = (size_t)el.idx * ((size_t)k.F + 1) + (size_t)b * 8;
+    if (k.width == 1) {
+        const u32x2_t q = ldg<u32x2_t>(k.bufs + base);
+        v[0] = q.x & 0xFF; v[1] = (q.x >> 8) & 0xFF; v[2] = (q.x >> 16) & 0xFF; v[3] = q.x >> 24;
+        v[4] = q.y & 0xFF; v[5] = (q.y >> 8) & 0xFF; v[6] = (q.y >> 16) & 0xFF; v[7] = q.y >> 24;
+    } else if (k.width == 2) {
+        const u32x4_t q = ldg<u32x4_t>(k.bufs + 2 * base);
+        v[0] = q.x & 0xFFFF; v[1] = q.x >> 16; v[2] = q.y & 0xFFFF; v[3] = q.y >> 16;
+        v[4] = q.z & 0xFFFF; v[5] = q.z >> 16; v[6] = q.w & 0xFFFF; v[7] = q.w >> 16;
+    } else if (k.width == 4) {
+        const u32x4_t q0 = ldg<u32x4_t>(k.bufs + 4 * base), q1 = ldg<u32x4_t>(k.bufs + 4 * base + 16);
+        v[0] = q0.x; v[1] = q0.y; v[2] = q0.z; v[3] = q0.w;
+        v[4] = q1.x; v[5] = q1.y; v[6] = q1.z; v[7] = q1.w;
+    } else {
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        switch (k.width) {
-            case 1: v[q] = ldg<uint8_t>(k.bufs + base + q); break;
-            case 2: v[q] = ldg<uint16_t>(k.bufs + 2 * (base + q)); break;
-            case 4: v[q] = ldg<uint32_t>(k.bufs + 4 * (base + q)); break;
-            default: v[q] = (uint32_t)ldg<u64>(k.bufs + 8 * (base + q)); break;
+        for (int q = 0; q < 8; q += 2) {  // uint64 tables: values fit 32 bits by contract (n_samples < 2^32)
+            const u32x4_t w = ldg<u32x4_t>(k.bufs + 8 * (base + q));
+            v[q] = w.x;
+            v[q + 1] = w.z;
         }
     }
 }
