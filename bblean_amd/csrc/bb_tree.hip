@@ -182,9 +182,11 @@ __host__ __device__ constexpr Smem smem_layout(int bf, int RB, int nm) {
 }
 
 // mirrored path levels for a (branching factor, row bytes) pair: as many (<= MAXM) as keep the
-// workgroup inside the CU's 160 KiB of LDS; only 2048-bit rows are mirrored
+// workgroup inside the CU's 160 KiB of LDS; rows of 512, 1024 and 2048 bits are mirrored
 __host__ __device__ constexpr int mirror_levels(int bf, int RB) {
-    if (RB != 256) return 0;
+    // a wave compares a quarter of the row in 16-byte pieces; the write-through of centroid updates
+    // is part of the one-byte-group-per-thread update path (row bytes <= threads)
+    if (RB % 64 != 0 || RB > TB) return 0;
     for (int q = MAXM; q >= 1; --q)
         if (smem_layout(bf, RB, q).total <= 160 * 1024) return q;
     return 0;
@@ -591,14 +593,24 @@ __device__ __forceinline__ Cand node_best(const KCt& k, int& cmp_par, uint32_t n
                     u32x4_t d;
                     if constexpr (ROOT) d = *(LA u32x4_t*)(k.L + k.o.rc_cent + (mrow0 + r) * k.RBS + ch * 16);
                     else d = ldg<u32x4_t>(k.cent + (meta + r) * (size_t)k.RB + ch * 16);
+                    if constexpr (!ROOT) {
+                        if (fill) *(LA u32x4_t*)(k.L + k.o.rc_cent + (mrow0 + r) * k.RBS + ch * 16) = d;
+                    }
                     part += popc4v(d & vec[ch]);
                 }
                 if (l == 0) {
                     if constexpr (ROOT) {
                         part += lds<uint32_t>(k.L, k.o.rc_card)[mrow0 + r] << 16;
                     } else {
-                        part += ldg<uint32_t>(k.card + meta + r) << 16;
-                        if (want_link) s_link[r] = ldg<uint32_t>(k.link + meta + r);
+                        const uint32_t cd = ldg<uint32_t>(k.card + meta + r);
+                        part += cd << 16;
+                        uint32_t lk = 0;
+                        if (want_link || fill) lk = ldg<uint32_t>(k.link + meta + r);
+                        if (want_link) s_link[r] = lk;
+                        if (fill) {
+                            lds<uint32_t>(k.L, k.o.rc_card)[mrow0 + r] = cd;
+                            lds<uint32_t>(k.L, k.o.rc_link)[mrow0 + r] = lk;
+                        }
                     }
                 }
             }
@@ -665,22 +677,28 @@ __device__ __forceinline__ Cand node_best_mirror(const KCt& k, int& cmp_par, uin
     LA uint32_t* pp = lds<uint32_t>(k.L, k.o.ppart) + (uint32_t)cmp_par * TW * k.rows;
     LA uint32_t* s_i = lds<uint32_t>(k.L, second ? k.o.i2 : k.o.i1);
     LA uint32_t* s_u = lds<uint32_t>(k.L, second ? k.o.u2 : k.o.u1);
-    // this wave's 64 bytes of the query vector (same address in every lane: LDS broadcast)
+    // this wave's quarter of the query vector (same address in every lane: LDS broadcast); rows of
+    // 64 / 128 / 256 bytes give 1 / 2 / 4 sixteen-byte pieces per wave
+    const int pieces = k.RB / 64;
+    const uint32_t slice = (uint32_t)k.RB / 4;
     u32x4_t xv[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) xv[i] = *(LA u32x4_t*)(k.L + vec_off + wave * 64 + i * 16);
+    for (int i = 0; i < 4; ++i)
+        if (i < pieces) xv[i] = *(LA u32x4_t*)(k.L + vec_off + wave * slice + i * 16);
     const uint32_t last = len - 1;  // len >= 1
     // loops run over the node's row slots (a compile-time count for KCFix), rows >= len are masked
     for (uint32_t r0 = 0; r0 < k.rows; r0 += 64) {
         const uint32_t r = r0 + lane;
         const uint32_t rc = r < last ? r : last;
-        const uint32_t base = k.o.rc_cent + (mrow0 + rc) * k.RBS + wave * 64;
+        const uint32_t base = k.o.rc_cent + (mrow0 + rc) * k.RBS + wave * slice;
         u32x4_t d[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) d[i] = *(LA u32x4_t*)(k.L + base + i * 16);
+        for (int i = 0; i < 4; ++i)
+            if (i < pieces) d[i] = *(LA u32x4_t*)(k.L + base + i * 16);
         uint32_t part = 0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) part += popc4v(d[i] & xv[i]);
+        for (int i = 0; i < 4; ++i)
+            if (i < pieces) part += popc4v(d[i] & xv[i]);
         if (r < len) pp[wave * k.rows + r] = part;
     }
     // a full barrier: it also orders the previous insertion's HBM stores before the RowMeta read
@@ -964,7 +982,7 @@ __device__ __forceinline__ void split_node(const KCt& k, const Elem& el, int& re
         mrm[2 * r + 1] = ldg<u32x4_t>((uint8_t*)(k.rm + meta + r) + 16);
     }
     if (lm && !ms_valid) {
-        const uint32_t total = m * 16u;
+        const uint32_t rbc = (uint32_t)k.RBc, total = m * rbc;  // 16-byte pieces of the node's rows
         for (uint32_t i0 = 0; i0 < total; i0 += 4 * TB) {  // four 16-byte pieces per thread in flight
             u32x4_t t4[4];
 #pragma unroll
@@ -975,7 +993,7 @@ __device__ __forceinline__ void split_node(const KCt& k, const Elem& el, int& re
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const uint32_t i = i0 + u * TB + tid;
-                if (i < total) *(LA u32x4_t*)(k.L + k.o.rc_cent + (mrow0 + (i >> 4)) * k.RBS + (i & 15u) * 16) = t4[u];
+                if (i < total) *(LA u32x4_t*)(k.L + k.o.rc_cent + (mrow0 + i / rbc) * k.RBS + (i % rbc) * 16) = t4[u];
             }
         }
     }
@@ -1461,7 +1479,7 @@ __device__ __forceinline__ void tree_insert_body(unsigned char* smem_raw, TreeDe
                     for (int q = 0; q < MAXM; ++q)
                         if (depth == q) mir_zero[q] = !anyc;
                 } else {
-                    const bool fill = depth < nm && k.RBc == 16;
+                    const bool fill = depth < nm;
                     best = node_best<false, false>(k, cmp_par, nd, -1, k.o.x, el.pcx, false, false, true, &len, &leaf,
                                                    (uint32_t)depth, fill, &anyc);
                     j = best.r;
@@ -1600,7 +1618,7 @@ __device__ __forceinline__ void tree_insert_body(unsigned char* smem_raw, TreeDe
                 }
                 uint8_t* crow = k.cent + (leafm + jl) * (size_t)k.RB;
                 u64 card = pcs[0];
-                const bool leaf_mirrored = D < nm && k.RBc == 16;  // the leaf node sits in LDS mirror D
+                const bool leaf_mirrored = D < nm;  // the leaf node sits in LDS mirror D
                 if (fast) {
                     if (act) {
                         cf_store8(k, slotN, b0, vL);
@@ -1665,7 +1683,7 @@ __device__ __forceinline__ void tree_insert_body(unsigned char* smem_raw, TreeDe
                     }
                 }
                 node_put_row(k, leafnode, leaflen, k.o.x, el.pcx, slotw, s, el.nS, slotw, el.s1S, el.s2S);
-                if (D < nm && k.RBc == 16) {  // the new row also goes into the leaf's LDS mirror
+                if (D < nm) {  // the new row also goes into the leaf's LDS mirror
                     const uint32_t mr = (uint32_t)D * k.rows + leaflen;
                     if (tid < k.RBc) *(LA u32x4_t*)(k.L + k.o.rc_cent + mr * k.RBS + tid * 16) = sx[tid];
                     if (tid == 0) {

@@ -42,10 +42,18 @@ def _same(a: BitBirch, b: BitBirch) -> None:
     ("diameter", 0.3, 50, 50_000, "sparse"),
     ("diameter", 0.6, 50, 20_000, "sparse"),
     ("tolerance-radius", 0.65, 8, 152_088, "tiers"),
+    ("diameter", 0.3, 50, 40_000, "width512"),    # mirrored, one 16-byte piece per wave
+    ("diameter", 0.3, 50, 40_000, "width1024"),   # mirrored, two pieces per wave
+    ("diameter", 0.3, 50, 60_000, "width4096"),   # not mirrored, several byte groups per thread
 ])
 def test_hip_tree_vs_oracle_large(crit, thr, bf, n, kind):
     if kind == "fake":
         fps = np.concatenate([make_fake_fingerprints(min(10_000, n), seed=500 + i) for i in range((n + 9999) // 10_000)])[:n]
+    elif kind.startswith("width"):
+        nf = int(kind[5:])
+        rng = np.random.default_rng(77)
+        dens = np.clip(rng.normal(750 / 2048, 400 / 2048, (n, 1)), 1 / nf, 1 - 1 / nf)
+        fps = np.packbits(rng.random((n, nf)) < dens, axis=1)
     elif kind == "tiers":
         # exact duplicates in three weight classes so that uint8, uint16 and uint32 cluster
         # features meet inside the same leaves and splits (bf 8: a split every few new rows)
