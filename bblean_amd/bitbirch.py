@@ -901,9 +901,9 @@ def fit_buffers_concurrently(
             continue
         engines = [t._engine for t in live]
         many = getattr(type(engines[0]), "fit_buffers_many", None)
-        if many is not None and all(type(e) is type(engines[0]) for e in engines):
+        if len(engines) > 1 and many is not None and all(type(e) is type(engines[0]) for e in engines):
             leaves = many(engines, [p[0] for p in prepared])
-        else:
+        else:  # a single tree takes the single-tree entry point (streamed input, singleton fast path)
             leaves = [e.fit_buffers(p[0]) for e, p in zip(engines, prepared)]
         for tree, leaf, (_, counts, flat) in zip(live, leaves, prepared):
             tree._commit_fit_buffers(leaf, counts, flat)

@@ -1844,6 +1844,25 @@ __global__ __launch_bounds__(TB, 2) void k_tree_insert_dense(TreeDev* trees) {
 using KC50 = KCFix<50, 2048>;
 using KC254 = KCFix<254, 2048>;
 
+// uint8 BitFeature buffers with n_samples == 1 are plain fingerprints in unpacked form (ls in {0, 1}):
+// pack them (MSB first, np.packbits order) so that they take the fingerprint path of the kernel.
+__global__ __launch_bounds__(256) void k_pack_singletons(const uint8_t* __restrict__ bufs, long long k, int F, int nbytes,
+                                                          uint8_t* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= k * nbytes) return;
+    const long long r = i / nbytes;
+    const int b = (int)(i % nbytes);
+    const uint8_t* src = bufs + (size_t)r * ((size_t)F + 1) + (size_t)b * 8;
+    const u32x2_t q = *(const GA u32x2_t*)src;  // unaligned 8-byte load
+    uint32_t byte = 0;
+#pragma unroll
+    for (int z = 0; z < 4; ++z) {
+        byte |= (((q.x >> (8 * z)) & 0xFFu) != 0 ? 1u : 0u) << (7 - z);
+        byte |= (((q.y >> (8 * z)) & 0xFFu) != 0 ? 1u : 0u) << (3 - z);
+    }
+    out[i] = (uint8_t)byte;
+}
+
 // =======================================================================================
 // Batch mode (exact, rollback-free): a prefix of the pending fingerprints is routed through the
 // STABLE upper levels of the tree in parallel (k_route), the host admits the longest prefix for
@@ -2528,6 +2547,52 @@ extern "C" int bbh_tree_fit_packed(bbh_tree* t, const uint8_t* rows, int64_t n, 
     return BBH_OK;
 }
 
+// Insert m uint8-wide BitFeature buffers that sit in HBM.  Runs of singletons (n_samples == 1, the
+// bulk of every table: 92 % of the BitFeatures of the 1 M-row benchmark) are packed on the device and
+// inserted as fingerprints - the same BitFeature (ls = bits, n = 1, centroid = the bits; reference
+// bitbirch.py:412-421 vs :422-448) through the cheaper path; everything else goes as buffers.
+// `n_col`: the n_samples column on the host.
+static int insert_u8_buffers(bbh_tree* t, const uint8_t* d, int64_t m, const uint8_t* n_col, uint32_t* out, hipStream_t s) {
+    const int64_t kMinRun = 1024;
+    const size_t row_bytes = (size_t)t->h.F + 1;
+    const int nbytes = t->h.nbytes;
+    uint8_t* packed = nullptr;
+    int rc = BBH_OK;
+    for (int64_t lo = 0; lo < m && rc == BBH_OK;) {
+        // extend a singleton run as far as it goes; otherwise collect buffers up to the next long singleton run
+        int64_t hi = lo;
+        while (hi < m && n_col[hi] == 1) ++hi;
+        if (hi - lo >= kMinRun) {
+            if (!packed) {
+                hipError_t e = bb::dev_alloc(&packed, (size_t)m * nbytes);
+                if (e != hipSuccess) return bb::fail(BBH_ERR_HIP, "dev_alloc: %s", hipGetErrorString(e));
+            }
+            const long long total = (long long)(hi - lo) * nbytes;
+            hipLaunchKernelGGL(k_pack_singletons, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, d + (size_t)lo * row_bytes,
+                               (long long)(hi - lo), t->h.F, nbytes, packed);
+            rc = run_insert(t, packed, nbytes, nullptr, 0, hi - lo, out ? out + lo : nullptr, s);
+            lo = hi;
+            continue;
+        }
+        // short singleton runs stay with their neighbours
+        int64_t run1 = 0;
+        hi = lo;
+        while (hi < m) {
+            run1 = n_col[hi] == 1 ? run1 + 1 : 0;
+            ++hi;
+            if (run1 >= kMinRun) { hi -= run1; break; }
+        }
+        if (hi == lo) hi = lo + 1;
+        rc = run_insert(t, nullptr, 0, d + (size_t)lo * row_bytes, 1, hi - lo, out ? out + lo : nullptr, s);
+        lo = hi;
+    }
+    if (packed) {
+        (void)hipStreamSynchronize(s);
+        bb::dev_free(packed);
+    }
+    return rc;
+}
+
 extern "C" int bbh_tree_fit_buffers(bbh_tree* t, const void* bufs, int32_t width, int64_t k, uint32_t* out_leaf,
                                     void* stream) {
     if (!t) return bb::fail(BBH_ERR_INVALID, "null tree");
@@ -2543,16 +2608,33 @@ extern "C" int bbh_tree_fit_buffers(bbh_tree* t, const void* bufs, int32_t width
     const size_t row_bytes = ((size_t)t->h.F + 1) * width;
     bb::DevOut o;
     BB_TRY(o.init(out_leaf, (size_t)k * 4));
+    static const bool no_singleton_path = getenv("BBHIP_NO_SINGLETON_PATH") != nullptr;
+    const bool split_runs = width == 1 && !no_singleton_path;
     if (bb::is_device_ptr(bufs)) {
-        BB_TRY(run_insert(t, nullptr, 0, (const uint8_t*)bufs, width, k, (uint32_t*)o.dev, s));
+        if (split_runs) {
+            std::vector<uint8_t> n_col((size_t)k);  // the n_samples column: one strided copy
+            BB_HIP(hipMemcpy2D(n_col.data(), 1, (const uint8_t*)bufs + t->h.F, row_bytes, 1, (size_t)k, hipMemcpyDeviceToHost));
+            BB_TRY(insert_u8_buffers(t, (const uint8_t*)bufs, k, n_col.data(), (uint32_t*)o.dev, s));
+        } else {
+            BB_TRY(run_insert(t, nullptr, 0, (const uint8_t*)bufs, width, k, (uint32_t*)o.dev, s));
+        }
     } else {
         HostSlabs slabs;
         BB_TRY(slabs.init(t->device, bufs, row_bytes, k));
+        std::vector<uint8_t> n_col;
         for (int64_t off = 0; off < k;) {
             const uint8_t* d = nullptr;
             int64_t m = 0;
             BB_TRY(slabs.acquire(off, &d, &m));
-            BB_TRY(run_insert(t, nullptr, 0, d, width, m, o.dev ? (uint32_t*)o.dev + off : nullptr, s));
+            uint32_t* o_off = o.dev ? (uint32_t*)o.dev + off : nullptr;
+            if (split_runs) {
+                n_col.resize((size_t)m);
+                const uint8_t* src = (const uint8_t*)bufs + (size_t)off * row_bytes + t->h.F;
+                for (int64_t i = 0; i < m; ++i) n_col[(size_t)i] = src[(size_t)i * row_bytes];
+                BB_TRY(insert_u8_buffers(t, d, m, n_col.data(), o_off, s));
+            } else {
+                BB_TRY(run_insert(t, nullptr, 0, d, width, m, o_off, s));
+            }
             off += m;
         }
     }
