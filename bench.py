@@ -96,6 +96,7 @@ def main() -> None:
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--k1-rows", type=int, default=8_000_000)
     ap.add_argument("--shards", type=int, default=512)
+    ap.add_argument("--multiround-files", type=int, default=64, help="0 skips the file-based multiround run")
     args = ap.parse_args()
 
     import numpy as np
@@ -223,6 +224,36 @@ def main() -> None:
                        "note": "multiround round 1 (reference multiround.py:401-422) with this many input files: "
                                "one workgroup per shard tree, one kernel launch; results equal per-shard fit"}
 
+    # the reference's answer for large sets, `bb multiround` (multiround.py:333-484), on this one GPU:
+    # the same rows as shard files; all shards of round 1 and all batches of the merge round share
+    # kernel launches, the final merge is one sequential tree
+    mr_stats = None
+    if args.multiround_files > 1 and rank == 0:
+        import tempfile
+
+        from bblean_amd.multiround import run_multiround_bitbirch
+
+        host = fps.cpu().numpy()
+        per = n // args.multiround_files
+        with tempfile.TemporaryDirectory() as d:
+            names = []
+            for i in range(args.multiround_files):
+                f = Path(d) / f"fps.{i:05d}.npy"
+                np.save(f, host[i * per:(i + 1) * per])
+                names.append(f)
+            out_dir = Path(d) / "out"
+            out_dir.mkdir()
+            t1 = time.perf_counter()
+            timer = run_multiround_bitbirch(names, out_dir, branching_factor=args.bf, threshold=args.threshold,
+                                            num_initial_processes=1, device=local_rank)
+            dt = time.perf_counter() - t1
+        mr_stats = {"files": args.multiround_files, "rows": per * args.multiround_files, "seconds": dt,
+                    "fingerprints_per_s": per * args.multiround_files / dt,
+                    "rounds_s": {k: round(v, 3) for k, v in timer.timings.items()},
+                    "note": "file-compatible multiround with the reference's defaults (full refinement, one merge "
+                            "round in bins of 10, tolerance-diameter merges); files on tmpfs/disk inside the timing"}
+        del host
+
     traffic = None
     pmc = REPO / "profiles" / "pmc_latest.json"
     if pmc.is_file():
@@ -287,6 +318,7 @@ def main() -> None:
                 "queries": nq2, "centroids": nc2, "avg_launch_ms": k2_ms,
             },
             "concurrent_shards": shard_stats,
+            "multiround_one_gpu": mr_stats,
         }
         if not args.no_cpu and world == 1:
             sample = min(args.cpu_sample, n)

@@ -11,7 +11,7 @@ OUT="/tmp/prof_$TAG"
 rm -rf "$OUT"; mkdir -p "$OUT" "$FINAL"
 export TMPDIR=/tmp
 cd /tmp
-CMD="python $ROOT/bench.py --steps 1 --warmup 0 --n-fps $NFPS --no-cpu --shards 0 --k1-rows $NFPS"
+CMD="python $ROOT/bench.py --steps 1 --warmup 0 --n-fps $NFPS --no-cpu --shards 0 --multiround-files 0 --k1-rows $NFPS"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o bench -- $CMD > "$OUT/bench_trace.log" 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o bench -- $CMD > "$OUT/bench_pmc_fetch.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o bench -- $CMD > "$OUT/bench_pmc_write.log" 2>&1
