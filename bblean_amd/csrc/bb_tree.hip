@@ -249,8 +249,17 @@ struct KCBase {
     const uint8_t* bufs; int width;
     int crit, tol_len; double thr, tolerance; const double* tol;
     LA unsigned char* L;
+    // kind of element a kernel instance inserts: 0 packed fingerprints only, 1 BitFeature buffers
+    // only, 2 decided at run time (`bufs` null or not).  The specialised instances drop the other
+    // path's code and registers (+13 % on fingerprints).
+    static constexpr int buf = 2;
+};
+template <class Base, int BUF>
+struct KCWith : Base {
+    static constexpr int buf = BUF;
 };
 struct KC : KCBase {
+    static constexpr bool dynamic_shape = true;
     int F, nb, RB, RBc, RBS;
     uint32_t rows, bf;
     int nm;  // mirrored levels
@@ -258,6 +267,7 @@ struct KC : KCBase {
 };
 template <int BF, int NF>
 struct KCFix : KCBase {
+    static constexpr bool dynamic_shape = false;
     static constexpr int F = NF, nb = NF / 8, RB = (NF / 8 + 15) / 16 * 16, RBc = RB / 16, RBS = RB + 16;
     static constexpr uint32_t rows = BF + 1, bf = BF;
     static constexpr int nm = mirror_levels(BF, RB);
@@ -408,7 +418,7 @@ __device__ __forceinline__ void cf32_load8(const KCt& k, uint32_t slotw, int b, 
 // linear-sum values of the element being inserted for features b*8 .. b*8+7
 template <class KCt>
 __device__ __forceinline__ void elem_cols(const KCt& k, const Elem& el, int b, uint32_t v[8]) {
-    if (k.bufs == nullptr) {  // fingerprint: bits of the packed row, MSB first
+    if (KCt::buf == 0 || (KCt::buf == 2 && k.bufs == nullptr)) {  // fingerprint: bits of the packed row, MSB first
         const uint32_t xb = lds<uint8_t>(k.L, k.o.x)[b];
 #pragma unroll
         for (int q = 0; q < 8; ++q) v[q] = (xb >> (7 - q)) & 1u;
@@ -1291,7 +1301,7 @@ __device__ __forceinline__ void tree_insert_body(unsigned char* smem_raw, TreeDe
     k.bufs = T->bufs; k.width = (int)uni((uint32_t)T->width);
     k.crit = (int)uni((uint32_t)T->crit); k.tol_len = (int)uni((uint32_t)T->tol_len); k.thr = T->thr; k.tolerance = T->tolerance; k.tol = T->tol_table;
     k.L = (LA unsigned char*)smem_raw;
-    if constexpr (std::is_same<KCt, KC>::value) {  // shape of the tree as run-time values
+    if constexpr (KCt::dynamic_shape) {  // shape of the tree as run-time values
         k.F = (int)uni((uint32_t)T->F); k.nb = (int)uni((uint32_t)T->nbytes); k.RB = (int)uni((uint32_t)T->RB); k.RBc = k.RB / 16; k.RBS = k.RB + 16;
         k.bf = uni((uint32_t)T->bf); k.rows = k.bf + 1;
         k.nm = (int)uni((uint32_t)T->use_root_cache);  // number of mirrored path levels
@@ -1303,7 +1313,8 @@ __device__ __forceinline__ void tree_insert_body(unsigned char* smem_raw, TreeDe
     const long long n_elems = SUB ? (long long)(uni(gate_off[blockIdx.x + 1]) - g_off) : T->n_elems;
     uint32_t* out_leaf = T->out_leaf;
     const uint32_t cap_nodes = uni(T->cap_nodes), cap8 = uni(T->cap8), cap16 = uni(T->cap16), cap32 = uni(T->cap32);
-    const bool bufmode = k.bufs != nullptr;
+    if constexpr (KCt::buf == 0) k.bufs = nullptr;
+    const bool bufmode = KCt::buf == 0 ? false : (KCt::buf == 1 ? true : k.bufs != nullptr);
     const int tid = threadIdx.x;
     const int nb = k.nb;
     const uint32_t bf = k.bf;
@@ -1843,6 +1854,10 @@ __global__ __launch_bounds__(TB, 2) void k_tree_insert_dense(TreeDev* trees) {
 // shapes with a specialised kernel (KCFix): the benchmark / test default and the CLI default
 using KC50 = KCFix<50, 2048>;
 using KC254 = KCFix<254, 2048>;
+using KC50P = KCWith<KC50, 0>;  // ... inserting packed fingerprints
+using KC50B = KCWith<KC50, 1>;  // ... inserting BitFeature buffers
+using KC254P = KCWith<KC254, 0>;
+using KC254B = KCWith<KC254, 1>;
 
 // uint8 BitFeature buffers with n_samples == 1 are plain fingerprints in unpacked form (ls in {0, 1}):
 // pack them (MSB first, np.packbits order) so that they take the fingerprint path of the kernel.
@@ -2175,10 +2190,13 @@ int configure(bbh_tree* t, int32_t bf, int32_t n_features) {
         BB_HIP(hipFuncSetAttribute((const void*)k_tree_insert<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->lds));
         BB_HIP(hipFuncSetAttribute((const void*)k_tree_insert<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->lds));
         BB_HIP(hipFuncSetAttribute((const void*)k_tree_insert_dense<KC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->lds));
-        BB_HIP(hipFuncSetAttribute((const void*)k_tree_insert<false, false, KC50>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->lds));
-        BB_HIP(hipFuncSetAttribute((const void*)k_tree_insert_dense<KC50>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->lds));
+        BB_HIP(hipFuncSetAttribute((const void*)k_tree_insert<false, false, KC50P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->lds));
+        BB_HIP(hipFuncSetAttribute((const void*)k_tree_insert<false, false, KC50B>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->lds));
+        BB_HIP(hipFuncSetAttribute((const void*)k_tree_insert_dense<KC50P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->lds));
+        BB_HIP(hipFuncSetAttribute((const void*)k_tree_insert_dense<KC50B>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->lds));
         BB_HIP(hipFuncSetAttribute((const void*)k_tree_insert<true, false, KC50>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->lds));
-        BB_HIP(hipFuncSetAttribute((const void*)k_tree_insert<false, false, KC254>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->lds));
+        BB_HIP(hipFuncSetAttribute((const void*)k_tree_insert<false, false, KC254P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->lds));
+        BB_HIP(hipFuncSetAttribute((const void*)k_tree_insert<false, false, KC254B>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->lds));
     }
     return BBH_OK;
 }
@@ -2267,14 +2285,21 @@ int run_insert_multi(std::vector<Job>& jobs, hipStream_t s) {
             else {
                 const bool dense = dense_launch(active.size(), lds);
                 const dim3 grid((unsigned)active.size()), block(TB);
-                if (dense && all50) hipLaunchKernelGGL(k_tree_insert_dense<KC50>, grid, block, lds, s, dptr);
+                const uint32_t* const nu = nullptr;
+                // every job of a launch is of one kind (the entry points are per kind)
+                bool packed = true, buffers = true;
+                for (size_t a = 0; a < active.size(); ++a) {
+                    packed = packed && jobs[active[a]].bufs == nullptr;
+                    buffers = buffers && jobs[active[a]].bufs != nullptr;
+                }
+                if (!packed && !buffers) all50 = all254 = false;
+                if (dense && all50 && packed) hipLaunchKernelGGL(k_tree_insert_dense<KC50P>, grid, block, lds, s, dptr);
+                else if (dense && all50) hipLaunchKernelGGL(k_tree_insert_dense<KC50B>, grid, block, lds, s, dptr);
                 else if (dense) hipLaunchKernelGGL(k_tree_insert_dense<KC>, grid, block, lds, s, dptr);
-                else if (all50)
-                    hipLaunchKernelGGL((k_tree_insert<false, false, KC50>), grid, block, lds, s, dptr, (const uint32_t*)nullptr,
-                                       (const uint32_t*)nullptr, (const uint32_t*)nullptr);
-                else if (all254)
-                    hipLaunchKernelGGL((k_tree_insert<false, false, KC254>), grid, block, lds, s, dptr, (const uint32_t*)nullptr,
-                                       (const uint32_t*)nullptr, (const uint32_t*)nullptr);
+                else if (all50 && packed) hipLaunchKernelGGL((k_tree_insert<false, false, KC50P>), grid, block, lds, s, dptr, nu, nu, nu);
+                else if (all50) hipLaunchKernelGGL((k_tree_insert<false, false, KC50B>), grid, block, lds, s, dptr, nu, nu, nu);
+                else if (all254 && packed) hipLaunchKernelGGL((k_tree_insert<false, false, KC254P>), grid, block, lds, s, dptr, nu, nu, nu);
+                else if (all254) hipLaunchKernelGGL((k_tree_insert<false, false, KC254B>), grid, block, lds, s, dptr, nu, nu, nu);
                 else
                     hipLaunchKernelGGL((k_tree_insert<false, false, KC>), grid, block, lds, s, dptr, (const uint32_t*)nullptr,
                                        (const uint32_t*)nullptr, (const uint32_t*)nullptr);
