@@ -253,10 +253,13 @@ struct KCBase {
     // only, 2 decided at run time (`bufs` null or not).  The specialised instances drop the other
     // path's code and registers (+13 % on fingerprints).
     static constexpr int buf = 2;
+    // merge criterion fixed at compile time (BBH_CRIT_*), or -1: read `crit` at run time
+    static constexpr int crit_fixed = -1;
 };
-template <class Base, int BUF>
+template <class Base, int BUF, int CRIT = -1>
 struct KCWith : Base {
     static constexpr int buf = BUF;
+    static constexpr int crit_fixed = CRIT;
 };
 struct KC : KCBase {
     static constexpr bool dynamic_shape = true;
@@ -824,7 +827,8 @@ template <class KCt>
 __device__ __forceinline__ bool merge_accept(const KCt& k, const Elem& el, int& red_slot, uint32_t slotT, u64 nT, u64 s1T,
                                              u64 s2T, u64 new_n, u64 s1n, u64 s2n) {
     const double thr = k.thr;
-    switch (k.crit) {
+    const int crit = KCt::crit_fixed >= 0 ? KCt::crit_fixed : k.crit;
+    switch (crit) {
         case BBH_CRIT_DIAMETER:
             return isim_from_moments(s1n, s2n, new_n) >= thr;
         case BBH_CRIT_TOL_DIAMETER: {
@@ -1858,6 +1862,12 @@ using KC50P = KCWith<KC50, 0>;  // ... inserting packed fingerprints
 using KC50B = KCWith<KC50, 1>;  // ... inserting BitFeature buffers
 using KC254P = KCWith<KC254, 0>;
 using KC254B = KCWith<KC254, 1>;
+// ... with the criteria of the standard pipelines: diameter for fingerprints (`fit`), tolerance-diameter
+// for BitFeature buffers (refine, merge rounds)
+using KC50PD = KCWith<KC50, 0, BBH_CRIT_DIAMETER>;
+using KC50BT = KCWith<KC50, 1, BBH_CRIT_TOL_DIAMETER>;
+using KC254PD = KCWith<KC254, 0, BBH_CRIT_DIAMETER>;
+using KC254BT = KCWith<KC254, 1, BBH_CRIT_TOL_DIAMETER>;
 
 // uint8 BitFeature buffers with n_samples == 1 are plain fingerprints in unpacked form (ls in {0, 1}):
 // pack them (MSB first, np.packbits order) so that they take the fingerprint path of the kernel.
@@ -2194,6 +2204,12 @@ int configure(bbh_tree* t, int32_t bf, int32_t n_features) {
         BB_HIP(hipFuncSetAttribute((const void*)k_tree_insert<false, false, KC50B>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->lds));
         BB_HIP(hipFuncSetAttribute((const void*)k_tree_insert_dense<KC50P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->lds));
         BB_HIP(hipFuncSetAttribute((const void*)k_tree_insert_dense<KC50B>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->lds));
+        BB_HIP(hipFuncSetAttribute((const void*)k_tree_insert<false, false, KC50PD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->lds));
+        BB_HIP(hipFuncSetAttribute((const void*)k_tree_insert<false, false, KC50BT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->lds));
+        BB_HIP(hipFuncSetAttribute((const void*)k_tree_insert_dense<KC50PD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->lds));
+        BB_HIP(hipFuncSetAttribute((const void*)k_tree_insert_dense<KC50BT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->lds));
+        BB_HIP(hipFuncSetAttribute((const void*)k_tree_insert<false, false, KC254PD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->lds));
+        BB_HIP(hipFuncSetAttribute((const void*)k_tree_insert<false, false, KC254BT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->lds));
         BB_HIP(hipFuncSetAttribute((const void*)k_tree_insert<true, false, KC50>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->lds));
         BB_HIP(hipFuncSetAttribute((const void*)k_tree_insert<false, false, KC254P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->lds));
         BB_HIP(hipFuncSetAttribute((const void*)k_tree_insert<false, false, KC254B>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->lds));
@@ -2293,7 +2309,18 @@ int run_insert_multi(std::vector<Job>& jobs, hipStream_t s) {
                     buffers = buffers && jobs[active[a]].bufs != nullptr;
                 }
                 if (!packed && !buffers) all50 = all254 = false;
-                if (dense && all50 && packed) hipLaunchKernelGGL(k_tree_insert_dense<KC50P>, grid, block, lds, s, dptr);
+                bool diam = true, told = true;  // every tree on the standard criterion of its element kind?
+                for (size_t a = 0; a < active.size(); ++a) {
+                    diam = diam && jobs[active[a]].t->h.crit == BBH_CRIT_DIAMETER;
+                    told = told && jobs[active[a]].t->h.crit == BBH_CRIT_TOL_DIAMETER;
+                }
+                if (dense && all50 && packed && diam) hipLaunchKernelGGL(k_tree_insert_dense<KC50PD>, grid, block, lds, s, dptr);
+                else if (dense && all50 && buffers && told) hipLaunchKernelGGL(k_tree_insert_dense<KC50BT>, grid, block, lds, s, dptr);
+                else if (!dense && all50 && packed && diam) hipLaunchKernelGGL((k_tree_insert<false, false, KC50PD>), grid, block, lds, s, dptr, nu, nu, nu);
+                else if (!dense && all50 && buffers && told) hipLaunchKernelGGL((k_tree_insert<false, false, KC50BT>), grid, block, lds, s, dptr, nu, nu, nu);
+                else if (!dense && all254 && packed && diam) hipLaunchKernelGGL((k_tree_insert<false, false, KC254PD>), grid, block, lds, s, dptr, nu, nu, nu);
+                else if (!dense && all254 && buffers && told) hipLaunchKernelGGL((k_tree_insert<false, false, KC254BT>), grid, block, lds, s, dptr, nu, nu, nu);
+                else if (dense && all50 && packed) hipLaunchKernelGGL(k_tree_insert_dense<KC50P>, grid, block, lds, s, dptr);
                 else if (dense && all50) hipLaunchKernelGGL(k_tree_insert_dense<KC50B>, grid, block, lds, s, dptr);
                 else if (dense) hipLaunchKernelGGL(k_tree_insert_dense<KC>, grid, block, lds, s, dptr);
                 else if (all50 && packed) hipLaunchKernelGGL((k_tree_insert<false, false, KC50P>), grid, block, lds, s, dptr, nu, nu, nu);
