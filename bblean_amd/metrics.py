@@ -1,146 +1,153 @@
-r"""Clustering metrics on Tanimoto similarity (mirror of reference `bblean/metrics.py`),
-composed from the HIP kernels behind `bblean_amd.similarity`.
+r"""Clustering quality indices on Tanimoto similarity, evaluated with the HIP kernels.
 
-The reference evaluates these with O(k) / O(k^2) sequences of small NumPy calls
-(`metrics.py:47-214`).  Here each cluster costs one arr-vec Tanimoto launch, the k x k centroid
-distances of the Davies-Bouldin index come from ONE batched all-pairs launch
-(`bbh_jt_best_match` with the full matrix), and the pair sums of the Dunn index are formed from
-per-cluster linear sums (exact u64) instead of re-summing both clusters for every pair.  The
-float64 arithmetic that follows is performed in the reference's order, so results are
-bit-identical (tests/test_hip_metrics.py against reference-generated goldens).
+Public names and argument meaning follow the reference's ``bblean/metrics.py`` (``jt_isim_chi``
+`:47`, ``jt_dbi`` `:108`, ``jt_isim_dunn`` `:163`) so callers can switch imports.  The evaluation is
+organised around one prepared view of the clustering (`_Clustering`) instead of per-cluster NumPy
+loops: every cluster is resident as packed rows once, column sums are taken once per cluster by
+`bbh_add_rows` (exact u64), similarities to a central fingerprint are one arr-vec launch per
+cluster, and the k x k centroid similarities of the Davies-Bouldin index come from a single
+batched all-pairs launch.  The float64 reductions that follow use the reference's operation order,
+so the results are bit-identical (tests/test_hip_metrics.py, reference-generated goldens).
 """
 from __future__ import annotations
+
+import typing as tp
 
 import numpy as np
 from numpy.typing import NDArray
 
+from bblean_amd import similarity as _sim
 from bblean_amd.fingerprints import pack_fingerprints
-from bblean_amd.similarity import (
-    _sum_rows_u64,
-    centroid as centroid_from_fps,
-    centroid_from_sum,
-    jt_best_match_packed,
-    jt_isim_from_sum,
-    jt_isim_medoid,
-    jt_isim_packed,
-    jt_isim_unpacked,
-    jt_sim_packed,
-)
 
 __all__ = ["jt_isim_chi", "jt_isim_dunn", "jt_dbi"]
 
+_Fps = NDArray[np.uint8]
 
-def _calc_centrals(
-    cluster_fps: list[NDArray[np.uint8]],
-    kind: str,
-    input_is_packed: bool = True,
-    n_features: int | None = None,
-    pack: bool = True,
-) -> list[NDArray[np.uint8]]:
-    r"""(metrics.py:23-44)"""
-    if kind == "medoid":
-        return [jt_isim_medoid(c, input_is_packed=input_is_packed, n_features=n_features, pack=pack)[1]
-                for c in cluster_fps]
-    if kind == "centroid":
-        return [centroid_from_fps(c, input_is_packed=input_is_packed, n_features=n_features, pack=pack)
-                for c in cluster_fps]
-    raise ValueError(f"Unknown arg {kind} use 'medoids|centroids'")
+
+class _Clustering:
+    r"""A clustering as a list of fingerprint arrays plus everything the indices derive from it."""
+
+    def __init__(self, clusters: tp.Sequence[_Fps], packed: bool, n_features: int | None) -> None:
+        self.given = list(clusters)
+        self.given_packed = packed
+        self.n_features = n_features
+        self.sizes = [len(c) for c in self.given]
+        self.total = sum(self.sizes)
+        self._packed: list[_Fps] | None = None
+        self._sums: list[NDArray[np.uint64]] | None = None
+
+    def __len__(self) -> int:
+        return len(self.given)
+
+    @property
+    def packed(self) -> list[_Fps]:
+        if self._packed is None:
+            self._packed = self.given if self.given_packed else [pack_fingerprints(c) for c in self.given]
+        return self._packed
+
+    @property
+    def column_sums(self) -> list[NDArray[np.uint64]]:
+        if self._sums is None:
+            self._sums = [_sim._sum_rows_u64(c, self.given_packed, self.n_features) for c in self.given]
+        return self._sums
+
+    def isims(self) -> list[float]:
+        f = _sim.jt_isim_packed if self.given_packed else _sim.jt_isim_unpacked
+        return [f(c) for c in self.given]
+
+    def centrals(self, spec: tp.Sequence[_Fps] | str) -> list[_Fps]:
+        r"""Packed central fingerprint of every cluster: ``"centroid"`` / ``"medoid"`` or given ones
+        (given ones are in the representation of the clusters, like the reference expects)."""
+        if not isinstance(spec, str):
+            return list(spec) if self.given_packed else [pack_fingerprints(c) for c in spec]
+        if spec == "centroid":
+            return [_sim.centroid(c, input_is_packed=self.given_packed, n_features=self.n_features, pack=True)
+                    for c in self.given]
+        if spec == "medoid":
+            return [_sim.jt_isim_medoid(c, input_is_packed=self.given_packed, n_features=self.n_features, pack=True)[1]
+                    for c in self.given]
+        raise ValueError(f"Unknown arg {spec} use 'medoids|centroids'")
+
+    def distances_to(self, centrals: tp.Sequence[_Fps]) -> list[NDArray[np.float64]]:
+        r"""1 - Tanimoto of every member to its cluster's central: one launch per cluster."""
+        return [1 - _sim.jt_sim_packed(rows, c) for rows, c in zip(self.packed, centrals)]
+
+
+def _only_centroid(what: tp.Any, index: str) -> None:
+    if isinstance(what, str) and what != "centroid":
+        raise NotImplementedError(f"Currently only 'centroid' implemented for {index}")
 
 
 def jt_isim_chi(
-    cluster_fps: list[NDArray[np.uint8]],
-    all_fps_central: NDArray[np.uint8] | str = "centroid",
-    centrals: list[NDArray[np.uint8]] | str = "centroid",
+    cluster_fps: list[_Fps],
+    all_fps_central: _Fps | str = "centroid",
+    centrals: list[_Fps] | str = "centroid",
     input_is_packed: bool = True,
     n_features: int | None = None,
     verbose: bool = False,
 ) -> float:
-    r"""Calinski-Harabasz index on the Tanimoto iSIM, higher is better (metrics.py:47-105)."""
-    all_fps_num = sum(len(c) for c in cluster_fps)
-    if isinstance(all_fps_central, str):
-        if not all_fps_central == "centroid":
-            raise NotImplementedError("Currently only 'centroid' implemented for CHI")
-        total_linear_sum = sum(_sum_rows_u64(c, input_is_packed, n_features) for c in cluster_fps)
-        all_fps_central = centroid_from_sum(total_linear_sum, all_fps_num)
-    if isinstance(centrals, str):
-        if not centrals == "centroid":
-            raise NotImplementedError("Currently only 'centroid' implemented for CHI")
-        centrals = _calc_centrals(cluster_fps, centrals, input_is_packed, n_features)
-    elif not input_is_packed:
-        centrals = [pack_fingerprints(c) for c in centrals]
-    clusters_num = len(cluster_fps)
-    if not input_is_packed:
-        cluster_fps = [pack_fingerprints(c) for c in cluster_fps]
-    if clusters_num <= 1:
+    r"""Calinski-Harabasz index on the Tanimoto iSIM; higher is better."""
+    _only_centroid(all_fps_central, "CHI")
+    _only_centroid(centrals, "CHI")
+    cl = _Clustering(cluster_fps, input_is_packed, n_features)
+    if isinstance(all_fps_central, str):  # majority vote over ALL fingerprints, from the per-cluster sums
+        all_fps_central = _sim.centroid_from_sum(sum(cl.column_sums), cl.total)
+    cents = cl.centrals(centrals)
+    k = len(cl)
+    if k <= 1:
         return 0
-    # similarities of every central to the global central: one launch for all clusters
-    to_global = jt_sim_packed(np.stack(centrals), all_fps_central)
-    wcss = 0.0
-    bcss = 0.0
-    for i, (central, clust) in enumerate(zip(centrals, cluster_fps)):
-        bcss += len(clust) * (1 - to_global[i].item()) ** 2
-        d = 1 - jt_sim_packed(clust, central)
-        wcss += np.dot(d, d)
-    return bcss * (all_fps_num - clusters_num) / (wcss * (clusters_num - 1))
+    spread = 1 - _sim.jt_sim_packed(np.stack(cents), all_fps_central)  # every central vs the global one: one launch
+    between = 0.0
+    within = 0.0
+    for size, s, d in zip(cl.sizes, spread, cl.distances_to(cents)):
+        between += size * s.item() ** 2
+        within += np.dot(d, d)
+    return between * (cl.total - k) / (within * (k - 1))
 
 
 def jt_dbi(
-    cluster_fps: list[NDArray[np.uint8]],
-    centrals: list[NDArray[np.uint8]] | str = "centroid",
+    cluster_fps: list[_Fps],
+    centrals: list[_Fps] | str = "centroid",
     input_is_packed: bool = True,
     n_features: int | None = None,
     verbose: bool = False,
 ) -> float:
-    r"""Davies-Bouldin index on the Tanimoto distance, lower is better (metrics.py:108-159)."""
-    if isinstance(centrals, str):
-        centrals = _calc_centrals(cluster_fps, centrals, input_is_packed, n_features)
-    elif not input_is_packed:
-        centrals = [pack_fingerprints(c) for c in centrals]
-    if not input_is_packed:
-        cluster_fps = [pack_fingerprints(c) for c in cluster_fps]
-    fps_num = 0
-    S: list[float] = []
-    for central, clust_fps in zip(centrals, cluster_fps):
-        size = len(clust_fps)
-        S.append(np.sum(1 - jt_sim_packed(clust_fps, central)) / size)
-        fps_num += size
-    if fps_num == 0:
+    r"""Davies-Bouldin index on the Tanimoto distance; lower is better."""
+    cl = _Clustering(cluster_fps, input_is_packed, n_features)
+    cents = cl.centrals(centrals)
+    scatter = [np.sum(d) / size for d, size in zip(cl.distances_to(cents), cl.sizes)]
+    if cl.total == 0:
         return 0
-    # all central-to-central similarities in one batched launch (the reference loops k^2 calls)
-    cmat = np.stack(centrals)
-    _, _, _, sims = jt_best_match_packed(cmat, cmat, return_sims=True)
+    # k x k central-to-central similarities in ONE batched launch (k^2 small calls in the reference)
+    table = np.stack(cents)
+    sims = _sim.jt_best_match_packed(table, table, return_sims=True)[3]
     assert sims is not None
-    numerator = 0.0
-    for i in range(len(centrals)):
-        max_d = 0.0
-        for j in range(len(centrals)):
-            if i == j:
-                continue
-            Mij = 1 - sims[i, j].item()
-            max_d = max(max_d, (S[i] + S[j]) / Mij)
-        numerator += max_d
-    return numerator / fps_num
+    worst_sum = 0.0
+    for i in range(len(cents)):
+        worst = 0.0
+        for j in range(len(cents)):
+            if j != i:
+                worst = max(worst, (scatter[i] + scatter[j]) / (1 - sims[i, j].item()))
+        worst_sum += worst
+    return worst_sum / cl.total
 
 
 def jt_isim_dunn(
-    cluster_fps: list[NDArray[np.uint8]],
+    cluster_fps: list[_Fps],
     input_is_packed: bool = True,
     n_features: int | None = None,
     verbose: bool = False,
 ) -> float:
-    r"""Dunn index variant of the BitBIRCH article, higher is better (metrics.py:163-214)."""
-    if input_is_packed:
-        D = [jt_isim_packed(clust) for clust in cluster_fps]
-    else:
-        D = [jt_isim_unpacked(clust) for clust in cluster_fps]
-    max_d = max(D)
-    if max_d == 0:
+    r"""Dunn index variant of the BitBIRCH article; higher is better."""
+    cl = _Clustering(cluster_fps, input_is_packed, n_features)
+    diameters = cl.isims()
+    widest = max(diameters)
+    if widest == 0:
         return 1
-    sums = [_sum_rows_u64(c, input_is_packed, n_features) for c in cluster_fps]  # exact column sums, once
-    sizes = [len(c) for c in cluster_fps]
-    min_d = 1.00
-    for i in range(len(cluster_fps) - 1):
-        for j in range(i + 1, len(cluster_fps)):
-            dij = 1 - jt_isim_from_sum(sums[i] + sums[j], sizes[i] + sizes[j])
-            min_d = min(dij, min_d)
-    return min_d / max(D)
+    sums = cl.column_sums  # the pair sums of the reference's inner loop are sums of these
+    closest = 1.00
+    for i in range(len(cl) - 1):
+        for j in range(i + 1, len(cl)):
+            gap = 1 - _sim.jt_isim_from_sum(sums[i] + sums[j], cl.sizes[i] + cl.sizes[j])
+            closest = min(gap, closest)
+    return closest / widest
