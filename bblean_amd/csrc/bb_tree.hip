@@ -1866,6 +1866,7 @@ using KC254B = KCWith<KC254, 1>;
 // for BitFeature buffers (refine, merge rounds)
 using KC50PD = KCWith<KC50, 0, BBH_CRIT_DIAMETER>;
 using KC50BT = KCWith<KC50, 1, BBH_CRIT_TOL_DIAMETER>;
+using KC50PT = KCWith<KC50, 0, BBH_CRIT_TOL_DIAMETER>;  // singleton runs of refine / merge rounds
 using KC254PD = KCWith<KC254, 0, BBH_CRIT_DIAMETER>;
 using KC254BT = KCWith<KC254, 1, BBH_CRIT_TOL_DIAMETER>;
 
@@ -2206,6 +2207,7 @@ int configure(bbh_tree* t, int32_t bf, int32_t n_features) {
         BB_HIP(hipFuncSetAttribute((const void*)k_tree_insert_dense<KC50B>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->lds));
         BB_HIP(hipFuncSetAttribute((const void*)k_tree_insert<false, false, KC50PD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->lds));
         BB_HIP(hipFuncSetAttribute((const void*)k_tree_insert<false, false, KC50BT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->lds));
+        BB_HIP(hipFuncSetAttribute((const void*)k_tree_insert<false, false, KC50PT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->lds));
         BB_HIP(hipFuncSetAttribute((const void*)k_tree_insert_dense<KC50PD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->lds));
         BB_HIP(hipFuncSetAttribute((const void*)k_tree_insert_dense<KC50BT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->lds));
         BB_HIP(hipFuncSetAttribute((const void*)k_tree_insert<false, false, KC254PD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->lds));
@@ -2318,6 +2320,7 @@ int run_insert_multi(std::vector<Job>& jobs, hipStream_t s) {
                 else if (dense && all50 && buffers && told) hipLaunchKernelGGL(k_tree_insert_dense<KC50BT>, grid, block, lds, s, dptr);
                 else if (!dense && all50 && packed && diam) hipLaunchKernelGGL((k_tree_insert<false, false, KC50PD>), grid, block, lds, s, dptr, nu, nu, nu);
                 else if (!dense && all50 && buffers && told) hipLaunchKernelGGL((k_tree_insert<false, false, KC50BT>), grid, block, lds, s, dptr, nu, nu, nu);
+                else if (!dense && all50 && packed && told) hipLaunchKernelGGL((k_tree_insert<false, false, KC50PT>), grid, block, lds, s, dptr, nu, nu, nu);
                 else if (!dense && all254 && packed && diam) hipLaunchKernelGGL((k_tree_insert<false, false, KC254PD>), grid, block, lds, s, dptr, nu, nu, nu);
                 else if (!dense && all254 && buffers && told) hipLaunchKernelGGL((k_tree_insert<false, false, KC254BT>), grid, block, lds, s, dptr, nu, nu, nu);
                 else if (dense && all50 && packed) hipLaunchKernelGGL(k_tree_insert_dense<KC50P>, grid, block, lds, s, dptr);
