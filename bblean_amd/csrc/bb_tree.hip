@@ -470,6 +470,21 @@ __device__ __forceinline__ uint32_t centroid_byte(const uint32_t v[8], u64 n) {
     return byte;
 }
 
+// the same for a BitFeature that has just absorbed another one: n >= 2 by construction, so the
+// "n <= 1: cast" case of centroid_from_sum cannot occur (one code variant less per inlined copy)
+__device__ __forceinline__ uint32_t centroid_byte_merged(const uint32_t v[8], u64 n) {
+    uint32_t byte = 0;
+    if (n <= 0x7FFFFFFFull) {
+        const uint32_t half = (uint32_t)((n + 1) >> 1);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) byte |= (v[q] >= half ? 1u : 0u) << (7 - q);
+    } else {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) byte |= (2ull * v[q] >= n ? 1u : 0u) << (7 - q);
+    }
+    return byte;
+}
+
 __device__ __forceinline__ uint32_t tier_for(u64 n) { return n <= 255 ? 0u : (n <= 65535 ? 1u : 2u); }
 __device__ __forceinline__ int ctr_for_tier(uint32_t tier) { return tier == 0 ? C_N8 : (tier == 1 ? C_N16 : C_N32); }
 
@@ -1594,14 +1609,14 @@ __device__ __forceinline__ void tree_insert_body(unsigned char* smem_raw, TreeDe
                     }
 #pragma unroll
                     for (int q = 0; q < 8; ++q) vL[q] += xs[q];
-                    byteL = centroid_byte(vL, new_n);
+                    byteL = centroid_byte_merged(vL, new_n);
                     pcs[0] = __popc(byteL);
 #pragma unroll
                     for (int q = 0; q < MAXFAST; ++q) {
                         if (q < DT) {
 #pragma unroll
                             for (int z = 0; z < 8; ++z) vT[q][z] += xs[z];
-                            byteT[q] = centroid_byte(vT[q], (u64)tn[q] + el.nS);
+                            byteT[q] = centroid_byte_merged(vT[q], (u64)tn[q] + el.nS);
                             pcs[1 + q] = __popc(byteT[q]);
                         }
                     }
