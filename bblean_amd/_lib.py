@@ -38,6 +38,7 @@ _PROTOTYPES = {
     "bbh_jt_arr_vec": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "bbh_jt_best_match": (_int, [_vp, _i64, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
     "bbh_unpack": (_int, [_vp, _i64, _i64, _i64, _vp, _vp]),
+    "bbh_pack": (_int, [_vp, _i64, _i64, _vp, _vp]),
     "bbh_add_rows": (_int, [_vp, _i64, _i64, _int, _i64, _vp, _vp]),
     "bbh_centroid_from_sum": (_int, [_vp, _i32, _i64, _i64, _int, _vp, _vp]),
     "bbh_isim_from_sum": (_int, [_vp, _i32, _i64, _i64, C.POINTER(_f64), C.POINTER(_int), _vp]),
@@ -61,6 +62,7 @@ _PROTOTYPES = {
     "bbh_profile_enable": (_int, [_int]),
     "bbh_profile_reset": (_int, []),
     "bbh_profile_get": (_int, [C.c_char_p, C.POINTER(_i64), C.POINTER(_f64)]),
+    "bbh_profile_units": (_int, [C.c_char_p, C.POINTER(_i64)]),
 }
 
 EXPORTED_SYMBOLS = tuple(_PROTOTYPES)

@@ -275,11 +275,18 @@ class BitBirch:
         )
 
     def _ensure_engine(self, n_features: int) -> None:
-        if self._engine is not None:
-            if n_features != self._n_features:
+        if self._engine is not None and n_features != self._n_features:
+            if self._is_init:
                 raise ValueError(
                     f"tree was built with n_features={self._n_features}, got {n_features}"
                 )
+            # a reset (or never fitted) tree is re-initialised for the new width, like the
+            # reference's _initialize_tree (bitbirch.py:880-884)
+            close = getattr(self._engine, "close", None)
+            if close is not None:
+                close()
+            self._engine = None
+        if self._engine is not None:
             self._push_merge_to_engine()
             return
         fn = self._merge_accept_fn
@@ -396,8 +403,17 @@ class BitBirch:
         ids) or None when there is nothing to insert."""
         if isinstance(X, (Path, str)):
             X = np.load(Path(X), mmap_mode="r")
-        nf = _validate_n_features(X, input_is_packed=False) - 1
-        if isinstance(X, list):
+        is_dev = hasattr(X, "raw") and hasattr(X, "n_samples")  # _engine.DevTable: a table resident in HBM
+        if is_dev:
+            if len(X) == 0:
+                raise ValueError("Input must have at least 1 fingerprint")
+            nf = X.shape[1] - 1
+            bufs = X
+        else:
+            nf = _validate_n_features(X, input_is_packed=False) - 1
+        if is_dev:
+            pass
+        elif isinstance(X, list):
             first = np.asarray(X[0])
             bufs = np.stack([np.asarray(b).astype(first.dtype, copy=False) for b in X])
         else:
@@ -418,16 +434,17 @@ class BitBirch:
             idx = _IndexLists.from_sequences(reinsert_index_seqs, k)
             check = True
         k = min(k, len(idx))
-        bufs = bufs[:k]
+        bufs = bufs.rows(0, k) if is_dev else bufs[:k]
         counts = idx.counts[:k]
         flat = idx.flat[: int(counts.sum())]
         if check and k:
-            bad = np.nonzero(counts != bufs[:, -1].astype(np.int64))[0]
+            n_col = (bufs.n_samples() if is_dev else bufs[:, -1]).astype(np.int64)
+            bad = np.nonzero(counts != n_col)[0]
             if bad.size:
                 i = int(bad[0])
                 raise ValueError(
                     "Expected len(mol_indices) == buffer[-1],"
-                    f" but found {int(counts[i])} != {int(bufs[i, -1])}"
+                    f" but found {int(counts[i])} != {int(n_col[i])}"
                 )
         self._is_init = True
         if not k:
@@ -656,15 +673,20 @@ class BitBirch:
         return groups
 
     def _bf_tables(
-        self, positions: NDArray[np.int64]
-    ) -> tuple[dict[str, NDArray[np.integer]], dict[str, _IndexLists]]:
+        self, positions: NDArray[np.int64], device: bool = False
+    ) -> tuple[dict[str, tp.Any], dict[str, _IndexLists]]:
         r"""Array form of `_bf_to_np`: per dtype group a (k, F+1) buffer table gathered
-        on the device and the member lists as CSR."""
+        on the device and the member lists as CSR.  `device`: the tables stay in HBM (`DevTable`)
+        when the engine can do that (multiround hands them to the next round / the exchange)."""
         lv = self._leaves()
-        bufs: dict[str, NDArray[np.integer]] = {}
+        bufs: dict[str, tp.Any] = {}
         mols: dict[str, _IndexLists] = {}
+        dev_ok = device and getattr(self._engine, "device_tables", False)
         for name, pos in self._group_positions(positions).items():
-            bufs[name] = self._engine.gather_buffers(pos, np.dtype(name).itemsize)
+            if dev_ok:
+                bufs[name] = self._engine.gather_buffers(pos, np.dtype(name).itemsize, device_out=True)
+            else:
+                bufs[name] = self._engine.gather_buffers(pos, np.dtype(name).itemsize)
             beg, end = lv["beg"][pos], lv["end"][pos]
             cnt = end - beg
             total = int(cnt.sum())
@@ -705,6 +727,10 @@ class BitBirch:
                 mol_idxs = mol_idxs[srt]
             elif isinstance(X, list):
                 fps = np.stack([np.asarray(X[i]) for i in arr_idxs])
+            elif hasattr(X, "data_ptr") and getattr(X, "is_cuda", False):  # device-resident shard
+                import torch
+
+                fps = X[torch.from_numpy(arr_idxs).to(X.device)].cpu().numpy()
             else:
                 fps = np.asarray(X)[arr_idxs]
             fps = np.asarray(fps)
@@ -868,7 +894,9 @@ def fit_concurrently(
         prepared.append(t._prepare_fit(X, ri, input_is_packed, n_features, max_fps))
     engines = [t._engine for t in trees]
     many = getattr(type(engines[0]), "fit_packed_many", None) if engines else None
-    if many is not None and all(type(e) is type(engines[0]) for e in engines):
+    # a single tree takes the single-tree entry point: host / file-backed rows are then streamed through
+    # two HBM slabs instead of being staged whole
+    if len(engines) > 1 and many is not None and all(type(e) is type(engines[0]) for e in engines):
         leaves = many(engines, [rows for rows, _ in prepared])
     else:
         leaves = [e.fit_packed(rows) for e, (rows, _) in zip(engines, prepared)]

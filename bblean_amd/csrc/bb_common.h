@@ -133,9 +133,11 @@ struct DevOut {
 struct ProfRec {
     hipEvent_t a, b;
     std::string name;
+    long long units = 0;  // work units of the launch (rows, inserted elements ...), for bbh_profile_units
 };
 extern bool g_prof_on;
 void prof_begin(const char* name, hipStream_t s, size_t* token);
+void prof_units(size_t token, long long units);
 void prof_end(size_t token, hipStream_t s);
 
 struct ProfScope {
@@ -143,6 +145,9 @@ struct ProfScope {
     hipStream_t s;
     ProfScope(const char* name, hipStream_t stream) : s(stream) {
         if (g_prof_on) prof_begin(name, stream, &tok);
+    }
+    void units(long long u) {
+        if (tok != (size_t)-1) prof_units(tok, u);
     }
     ~ProfScope() {
         if (tok != (size_t)-1) prof_end(tok, s);

@@ -30,6 +30,11 @@ void prof_begin(const char* name, hipStream_t s, size_t* token) {
     *token = g_prof.size() - 1;
 }
 
+void prof_units(size_t token, long long units) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (token < g_prof.size()) g_prof[token].units += units;
+}
+
 void prof_end(size_t token, hipStream_t s) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     if (token < g_prof.size()) (void)hipEventRecord(g_prof[token].b, s);
@@ -529,6 +534,46 @@ extern "C" int bbh_unpack(const uint8_t* packed, int64_t n, int64_t nbytes, int6
     return BBH_OK;
 }
 
+// np.packbits(axis=-1), MSB first (fingerprints.py:46-49): one thread per output byte
+__global__ void k_pack(const uint8_t* __restrict__ in, int64_t n, int64_t n_features, int64_t out_bytes,
+                       uint8_t* __restrict__ out) {
+    const int64_t total = n * out_bytes;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = t / out_bytes, b = t % out_bytes;
+        const uint8_t* src = in + row * n_features + b * 8;
+        const int64_t left = n_features - b * 8;  // the last byte is zero-padded like np.packbits
+        uint32_t v = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (k < left) v |= (src[k] != 0 ? 1u : 0u) << (7 - k);
+        out[t] = (uint8_t)v;
+    }
+}
+
+extern "C" int bbh_pack(const uint8_t* unpacked, int64_t n, int64_t n_features, uint8_t* out, void* stream) {
+    BB_TRY(bb::ensure_device());
+    if (n < 0 || n_features <= 0) return bb::fail(BBH_ERR_INVALID, "Input array must be 1- or 2-dimensional");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t out_bytes = (n_features + 7) / 8;
+    bb::DevIn a;
+    bb::DevOut o;
+    BB_TRY(a.init(unpacked, (size_t)(n * n_features), s));
+    BB_TRY(o.init(out, (size_t)(n * out_bytes)));
+    if (n > 0) {
+        bb::ProfScope ps("pack", s);
+        ps.units(n);
+        int64_t blocks = (n * out_bytes + 255) / 256;
+        if (blocks > 65535 * 16) blocks = 65535 * 16;
+        hipLaunchKernelGGL(k_pack, dim3((unsigned)blocks), dim3(256), 0, s, (const uint8_t*)a.dev, n, n_features, out_bytes,
+                           (uint8_t*)o.dev);
+        BB_HIP(hipGetLastError());
+    }
+    BB_TRY(o.finish(s));
+    if (a.owned || o.needs_copy()) BB_HIP(hipStreamSynchronize(s));
+    return BBH_OK;
+}
+
 // column sums: thread per output byte-group (8 columns when packed, 1 column otherwise),
 // rows split over gridDim.y, partials combined with 64-bit atomics.
 __global__ void k_add_rows_packed(const uint8_t* __restrict__ arr, int64_t n, int64_t nbytes,
@@ -850,6 +895,15 @@ extern "C" int bbh_profile_reset(void) {
         (void)hipEventDestroy(r.b);
     }
     bb::g_prof.clear();
+    return BBH_OK;
+}
+
+extern "C" int bbh_profile_units(const char* name, int64_t* units) {
+    std::lock_guard<std::mutex> lk(bb::g_prof_mu);
+    int64_t u = 0;
+    for (auto& r : bb::g_prof)
+        if (r.name == name) u += r.units;
+    if (units) *units = u;
     return BBH_OK;
 }
 

@@ -2296,10 +2296,12 @@ int run_insert_multi(std::vector<Job>& jobs, hipStream_t s) {
             harr[a] = h;
         }
         TreeDev* dptr = single ? jobs[0].t->d : darr;
+        size_t prof_tok = (size_t)-1;
         hipError_t e = hipMemcpyAsync(dptr, harr.data(), active.size() * sizeof(TreeDev), hipMemcpyHostToDevice, s);
         if (e != hipSuccess) { rc = bb::fail(BBH_ERR_HIP, "H2D: %s", hipGetErrorString(e)); break; }
         {
             bb::ProfScope ps("tree_insert", s);
+            prof_tok = ps.tok;
             static const bool prof_phases = getenv("BBHIP_PHASES") != nullptr;
             // trees of the benchmark / default shape run the kernel compiled for that shape
             static const bool no_fix = getenv("BBHIP_NO_FIXED_SHAPE") != nullptr;
@@ -2364,6 +2366,7 @@ int run_insert_multi(std::vector<Job>& jobs, hipStream_t s) {
             std::memcpy(h.phase, back.phase, sizeof(h.phase));
             std::memcpy(h.sphase, back.sphase, sizeof(h.sphase));
             j.done += back.processed;
+            if (prof_tok != (size_t)-1) bb::prof_units(prof_tok, back.processed);  // elements this launch inserted
             j.stalls = back.processed == 0 ? j.stalls + 1 : 0;
             if (j.stalls > 3) { rc = bb::fail(BBH_ERR_CAPACITY, "tree engine made no progress (stop reason %d)", back.stop_reason); break; }
             const int64_t left = j.n - j.done;

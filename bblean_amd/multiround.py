@@ -59,20 +59,32 @@ def _bits_of(name: str) -> int:
     return int(name.split("uint")[-1].split(".")[0])  # multiround.py:108
 
 
-def _file_rows(path: Path) -> int:
+def _file_rows(path: tp.Any) -> int:
+    if isinstance(path, ShardRows):
+        return path.n
+    if not isinstance(path, (Path, str)):
+        return int(path.shape[0])  # an array / device tensor holding the shard
     with open(path, "rb") as f:
         major, minor = np.lib.format.read_magic(f)
         shape, _, _ = getattr(np.lib.format, f"read_array_header_{major}_{minor}")(f)
     return shape[0]
 
 
-def _files_range_tuples(files: tp.Sequence[Path]) -> list[tuple[str, Path, int, int]]:
+class ShardRows:
+    r"""Placeholder for a shard another rank owns: only its row count is needed here (global molecule
+    index ranges, reference multiround.py:316-327)."""
+
+    def __init__(self, n: int) -> None:
+        self.n = int(n)
+
+
+def _files_range_tuples(files: tp.Sequence[tp.Any]) -> list[tuple[str, tp.Any, int, int]]:
     r"""(label, file, first global index, end) per shard (multiround.py:316-327)."""
     out, run = [], 0
     z = len(str(len(files)))
     for i, f in enumerate(files):
         n = _file_rows(f)
-        out.append((str(i).zfill(z), Path(f), run, run + n))
+        out.append((str(i).zfill(z), Path(f) if isinstance(f, (Path, str)) else f, run, run + n))
         run += n
     return out
 
@@ -101,12 +113,13 @@ def _initial_rounds(
     infos: tp.Sequence[tuple[str, Path, int, int]], *, branching_factor: int, threshold: float, tolerance: float,
     merge_criterion: str, refinement: str, refine_merge_criterion: str, refine_threshold_change: float,
     n_features: int | None, input_is_packed: bool, max_fps: int | None, engine_factory: tp.Any, device: int,
+    device_tables: bool = False,
 ) -> list[Tables]:
     r"""`_InitialRound.__call__` (multiround.py:175-216) for several shards at once, returning tables
     instead of files.  Every step that touches the device runs for all shards of a group in one
     launch; the per-shard results are those of the reference's one-process-per-shard pool."""
     out: list[Tables] = []
-    sizes = [max(int(Path(f).stat().st_size), 1) for _, f, _, _ in infos]
+    sizes = [max(int(Path(f).stat().st_size) if isinstance(f, Path) else int(np.prod(f.shape)), 1) for _, f, _, _ in infos]
     for grp in _groups(sizes):
         part = [infos[i] for i in grp]
         trees = [BitBirch(branching_factor=branching_factor, threshold=threshold, merge_criterion=merge_criterion,
@@ -116,7 +129,7 @@ def _initial_rounds(
         for t in trees:
             t.delete_internal_nodes()
         if refinement == "none":
-            out.extend(t._bf_tables(t._leaf_order(True)) for t in trees)
+            out.extend(t._bf_tables(t._leaf_order(True), device=device_tables) for t in trees)
             continue
         tabs = [t._refine_tables(f, initial_mol=s, input_is_packed=input_is_packed) for t, (_, f, s, _) in zip(trees, part)]
         if refinement == "full":
@@ -126,7 +139,7 @@ def _initial_rounds(
             fit_buffers_concurrently(trees, [[(bufs[name], mols[name]) for name in bufs] for bufs, mols in tabs])
             for t in trees:
                 t.delete_internal_nodes()
-            tabs = [t._bf_tables(t._leaf_order(True)) for t in trees]
+            tabs = [t._bf_tables(t._leaf_order(True), device=device_tables) for t in trees]
         out.extend(tabs)
     return out
 
@@ -139,7 +152,7 @@ def _merge_rounds(
     batch, rebuilt from the batch's BitFeature tables in the given order, all trees in shared launches."""
     trees = [BitBirch(branching_factor=branching_factor, threshold=threshold, merge_criterion=criterion,
                       tolerance=tolerance, device=device, _engine_factory=engine_factory) for _ in batches]
-    sizes = [sum(int(np.asarray(b).nbytes) for b, _ in batch) + 1 for batch in batches]
+    sizes = [sum(int(b.nbytes) for b, _ in batch) + 1 for batch in batches]
     for grp in _groups(sizes):
         fit_buffers_concurrently([trees[i] for i in grp], [list(batches[i]) for i in grp])
     for t in trees:
@@ -271,55 +284,126 @@ def _write_outputs(out_dir: Path, tree: BitBirch, save_centroids: bool) -> None:
 # one process per GPU
 # ------------------------------------------------------------------------------------------
 _CODE = {"uint8": 8, "uint16": 16, "uint32": 32, "uint64": 64}
+_NAME = {v: k for k, v in _CODE.items()}
+
+# one table on its way between rounds: (label, dtype name, table [k, F+1] (host array or DevTable), members)
+Entry = tuple[str, str, tp.Any, _IndexLists]
 
 
-def _allgather_tables(
-    mine: list[tuple[str, str, NDArray[np.integer], _IndexLists]], dist: tp.Any, device: tp.Any
-) -> list[tuple[str, str, NDArray[np.integer], _IndexLists]]:
-    r"""Variable-size all-gather of (label, dtype, table, member lists) entries: one
-    all-gather of the per-rank descriptors, then one padded all-gather per payload kind (table
-    bytes, member counts, member ids).  With backend "nccl" this is RCCL over xGMI."""
-    import torch
+def _entry_key(label: str, name: str) -> str:
+    # the order sorted(glob("round-*-bufs*.npy")) gives: by file name = (label, uintNN)
+    return f"label-{label}-{name.replace('8', '08')}"
 
-    world = dist.get_world_size()
-    desc = [(lab, name, int(t.shape[0]), int(t.shape[1]), int(idx.flat.size)) for lab, name, t, idx in mine]
-    all_desc: list[tp.Any] = [None] * world
-    dist.all_gather_object(all_desc, desc)
 
-    def gather_bytes(chunks: list[NDArray], dtype: tp.Any) -> list[NDArray]:
-        flat = np.concatenate([np.ascontiguousarray(c).view(np.uint8).reshape(-1) for c in chunks]) if chunks \
-            else np.zeros(0, dtype=np.uint8)
-        sizes = [None] * world
-        dist.all_gather_object(sizes, int(flat.size))
-        cap = max(max(sizes), 1)
-        send = torch.zeros(cap, dtype=torch.uint8, device=device)
-        if flat.size:
-            send[: flat.size] = torch.from_numpy(flat).to(device)
-        recv = [torch.empty(cap, dtype=torch.uint8, device=device) for _ in range(world)]
-        dist.all_gather(recv, send)
-        return [r[: sizes[i]].cpu().numpy().view(dtype) for i, r in enumerate(recv)]
+class _Exchange:
+    r"""Moves BitFeature tables between ranks for the next round: every table goes to the ONE rank that
+    merges it (point-to-point, `batch_isend_irecv`), never to the others.
 
-    tables_b = gather_bytes([t for _, _, t, _ in mine], np.uint8)
-    counts_b = gather_bytes([idx.counts.astype(np.int64) for *_, idx in mine], np.int64)
-    ids_b = gather_bytes([idx.flat.astype(np.int64) for *_, idx in mine], np.int64)
-    out = []
-    for r in range(world):
-        tb, cb, ib = tables_b[r], counts_b[r], ids_b[r]
-        to, co, io = 0, 0, 0
-        for lab, name, k, cols, nids in all_desc[r]:
-            item = np.dtype(name).itemsize
-            table = tb[to: to + k * cols * item].view(np.dtype(name)).reshape(k, cols)
-            to += k * cols * item
-            cnt = cb[co: co + k]
-            co += k
-            ids = ib[io: io + nids]
-            io += nids
-            out.append((lab, name, table, _IndexLists(cnt.copy(), ids.copy())))
-    return out
+    1. descriptors: one fixed-size int64 all-gather (label, dtype bits, rows, columns, member ids) -
+       no pickles;
+    2. every rank derives the same global plan from them: entries in the reference's file order
+       (`sorted(glob("round-*"))`, multiround.py:91-101), chunked into batches of `bin_size`, batch b
+       merged by rank `owner(b)`;
+    3. payloads: the table bytes, the member counts and the member ids (CSR) as three tensors per
+       entry, sent straight from where they lie (HBM for `DevTable`s - with backend "nccl" that is
+       RCCL over xGMI, GPU to GPU) and received into the buffer `fit_buffers` will read.
+    """
+
+    def __init__(self, dist: tp.Any, tdev: tp.Any, table_dev: tp.Any = None) -> None:
+        # tdev: where the wire tensors live (cuda for "nccl", cpu for "gloo"); table_dev: the GPU received
+        # tables are handed to the engine on (None: host arrays, the CPU oracle of the tests)
+        self.dist, self.tdev, self.table_dev = dist, tdev, table_dev
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self.bytes_sent = 0
+        self.bytes_received = 0
+
+    def _wire(self, a: tp.Any) -> tp.Any:
+        import torch
+
+        if hasattr(a, "raw"):  # DevTable
+            t = a.raw.reshape(-1)
+        else:
+            t = torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1))
+        return t if t.device == self.tdev else t.to(self.tdev)
+
+    def run(self, mine: list[Entry], bin_size: int | None, owner: tp.Callable[[int], int],
+            z_width: int | None = None) -> tuple[list[tuple[int, list[Entry]]], int]:
+        r"""Returns ([(batch index, entries of that batch in file order) for the batches this rank
+        merges], total number of batches).  `bin_size=None`: one batch with everything."""
+        import torch
+
+        from bblean_amd._engine import DevTable
+
+        dist, world, rank = self.dist, self.world, self.rank
+        on_dev = self.tdev.type == "cuda"
+        # 1. descriptors
+        cnt = torch.tensor([len(mine)], dtype=torch.int64, device=self.tdev)
+        cnts = [torch.zeros(1, dtype=torch.int64, device=self.tdev) for _ in range(world)]
+        dist.all_gather(cnts, cnt)
+        counts = [int(c.item()) for c in cnts]
+        cap = max(max(counts), 1)
+        desc = torch.zeros((cap, 6), dtype=torch.int64)
+        for i, (lab, name, table, idx) in enumerate(mine):
+            desc[i] = torch.tensor([int(lab), len(lab), _CODE[name], int(table.shape[0]), int(table.shape[1]),
+                                    int(idx.flat.size)], dtype=torch.int64)
+        desc = desc.to(self.tdev)
+        all_desc = [torch.zeros((cap, 6), dtype=torch.int64, device=self.tdev) for _ in range(world)]
+        dist.all_gather(all_desc, desc)
+        plan = []  # (key, src rank, src position, label, name, k, cols, n ids)
+        for r in range(world):
+            rows = all_desc[r].cpu().numpy()
+            for i in range(counts[r]):
+                lab_i, lab_w, bits, k, cols, nids = (int(v) for v in rows[i])
+                lab, name = str(lab_i).zfill(lab_w), _NAME[bits]
+                plan.append((_entry_key(lab, name), r, i, lab, name, k, cols, nids))
+        plan.sort(key=lambda e: e[0])
+        # 2. batches and their owners
+        chunks = [plan] if bin_size is None else [list(c) for c in batched(plan, bin_size)]
+        # 3. payloads
+        ops, recv_into = [], {}
+        mine_out: dict[int, list[tp.Any]] = {}
+        for b, chunk in enumerate(chunks):
+            dst = owner(b)
+            for pos, (_, src, i, lab, name, k, cols, nids) in enumerate(chunk):
+                item = np.dtype(name).itemsize
+                if src == rank and dst == rank:
+                    mine_out.setdefault(b, []).append((pos, mine[i]))
+                elif src == rank:
+                    _, _, table, idx = mine[i]
+                    parts = [self._wire(table), self._wire(idx.counts.astype(np.int64)), self._wire(idx.flat.astype(np.int64))]
+                    for t in parts:
+                        if t.numel():
+                            ops.append(dist.P2POp(dist.isend, t, dst))
+                            self.bytes_sent += int(t.numel())
+                elif dst == rank:
+                    tb = torch.empty((k, cols * item), dtype=torch.uint8, device=self.tdev)
+                    cb = torch.empty(k * 8, dtype=torch.uint8, device=self.tdev)
+                    ib = torch.empty(nids * 8, dtype=torch.uint8, device=self.tdev)
+                    for t in (tb, cb, ib):
+                        if t.numel():
+                            ops.append(dist.P2POp(dist.irecv, t.reshape(-1), src))
+                            self.bytes_received += int(t.numel())
+                    recv_into[(b, pos)] = (lab, name, tb, cb, ib, k, cols)
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+            if on_dev:
+                torch.cuda.synchronize()
+        for (b, pos), (lab, name, tb, cb, ib, k, cols) in recv_into.items():
+            cnt_np = cb.cpu().numpy().view(np.int64).copy()
+            ids_np = ib.cpu().numpy().view(np.int64).copy()
+            table: tp.Any
+            if self.table_dev is not None:  # stays a tensor end to end (gloo cannot carry device tensors: staged)
+                table = DevTable(tb if tb.device == self.table_dev else tb.to(self.table_dev), np.dtype(name).itemsize)
+            else:
+                table = tb.numpy().view(np.dtype(name)).reshape(k, cols)
+            mine_out.setdefault(b, []).append((pos, (lab, name, table, _IndexLists(cnt_np, ids_np))))
+        out = [(b, [e for _, e in sorted(v, key=lambda pe: pe[0])]) for b, v in sorted(mine_out.items())]
+        return out, len(chunks)
 
 
 def run_multiround_distributed(
-    input_files: tp.Sequence[Path],
+    input_files: tp.Sequence[tp.Any],
     out_dir: Path | None = None,
     *,
     n_features: int | None = None,
@@ -337,11 +421,22 @@ def run_multiround_distributed(
     save_centroids: bool = True,
     max_fps: int | None = None,
     device: int | None = None,
+    return_tree: bool = False,
     _engine_factory: tp.Any = None,
-) -> tuple[list[list[int]] | None, _Timer]:
-    r"""Multiround with one rank per GPU (`torch.distributed` must be initialised).  Returns
-    (clusters on rank 0 / None elsewhere, timings); also writes clusters.pkl on rank 0 when
-    `out_dir` is given."""
+) -> tuple[tp.Any, _Timer]:
+    r"""Multiround (reference multiround.py:333-484) with one rank per GPU (`torch.distributed` must be
+    initialised; backend "nccl" = RCCL over xGMI, "gloo" in the CPU tests).
+
+    `input_files[s]` is shard s: a ``.npy`` path, a packed array, a device-resident ``torch.uint8``
+    tensor, or `ShardRows(n)` for a shard this rank does not own (rank r owns shards r, r+W, ...).
+    Round 1 has no collective.  Between rounds the leaf BitFeature tables go, device to device, to the one
+    rank that merges them (`_Exchange`); batch composition and order are the reference's (name-sorted
+    tables chunked by `bin_size`, uint16 tables before uint8 inside a mid-round batch, plain name order
+    in the final round), so the clusters equal the file-based run's and the reference's for any number of
+    ranks.  Returns (clusters on rank 0 - or the final tree with `return_tree` - / None elsewhere,
+    timings); writes clusters.pkl on rank 0 when `out_dir` is given.  `timer.exchange` holds the bytes
+    this rank sent / received per round.
+    """
     import torch
     import torch.distributed as dist
 
@@ -349,59 +444,67 @@ def run_multiround_distributed(
         final_merge_criterion = midsection_merge_criterion
     rank, world = dist.get_rank(), dist.get_world_size()
     on_gpu = dist.get_backend() == "nccl"
-    dev_index = (torch.cuda.current_device() if device is None else device) if on_gpu else 0
+    dev_index = (torch.cuda.current_device() if device is None else device) if on_gpu else (device or 0)
     tdev = torch.device("cuda", dev_index) if on_gpu else torch.device("cpu")
+    # BitFeature tables stay in HBM between rounds whenever the engine is the HIP engine
+    dev_tables = _engine_factory is None and torch.cuda.is_available()
+    table_dev = torch.device("cuda", dev_index) if dev_tables else None
+    if dev_tables:
+        torch.cuda.set_device(dev_index)
     common = dict(branching_factor=branching_factor, tolerance=tolerance, engine_factory=_engine_factory, device=dev_index)
     timer = _Timer()
+    timer.exchange = {}  # type: ignore[attr-defined]
     timer.init_timing("total")
 
     # round 1: rank r owns shards r, r+W, ...  (no collective)
     timer.init_timing("round-1")
-    infos = _files_range_tuples([Path(f) for f in input_files])
-    mine = []
+    infos = _files_range_tuples(list(input_files))
+    mine: list[Entry] = []
     my_infos = [info for i, info in enumerate(infos) if i % world == rank]
     for info, (bufs, mols) in zip(my_infos, _initial_rounds(
             my_infos, threshold=threshold, merge_criterion=initial_merge_criterion,
             refinement=refinement_before_midsection, refine_merge_criterion=midsection_merge_criterion,
             refine_threshold_change=midsection_threshold_change, n_features=n_features,
-            input_is_packed=input_is_packed, max_fps=max_fps, **common)):
+            input_is_packed=input_is_packed, max_fps=max_fps, device_tables=dev_tables, **common)):
         for name in bufs:
             mine.append((info[0], name, bufs[name], mols[name]))
     timer.end_timing("round-1")
-
-    def ordered(entries: list) -> list:
-        # the order sorted(glob("round-*-bufs*.npy")) gives: by file name = (label, uintNN)
-        return sorted(entries, key=lambda e: f"label-{e[0]}-{e[1].replace('8', '08')}")
 
     round_idx = 1
     for _ in range(num_midsection_rounds):
         round_idx += 1
         timer.init_timing(f"round-{round_idx}")
-        everything = ordered(_allgather_tables(mine, dist, tdev))
-        z = len(str(math.ceil(len(everything) / bin_size)))
+        ex = _Exchange(dist, tdev, table_dev)
+        my_batches, n_batches = ex.run(mine, bin_size, lambda b: b % world)
+        timer.exchange[f"round-{round_idx}"] = {"sent": ex.bytes_sent, "received": ex.bytes_received}  # type: ignore[attr-defined]
+        z = len(str(n_batches))
         mine = []
-        my_batches = [(b, sorted(batch, key=lambda e: _CODE[e[1]], reverse=True))  # uint16 tables first
-                      for b, batch in enumerate(batched(everything, bin_size)) if b % world == rank]
-        trees = _merge_rounds([[(t, idx) for _, _, t, idx in batch] for _, batch in my_batches],
+        ordered = [(b, sorted(batch, key=lambda e: _CODE[e[1]], reverse=True)) for b, batch in my_batches]  # uint16 first
+        trees = _merge_rounds([[(t, idx) for _, _, t, idx in batch] for _, batch in ordered],
                               threshold=threshold + midsection_threshold_change,
                               criterion=midsection_merge_criterion, **common)
-        for (b, _), tree in zip(my_batches, trees):
-            bufs, mols = tree._bf_tables(tree._leaf_order(True))
+        for (b, _), tree in zip(ordered, trees):
+            bufs, mols = tree._bf_tables(tree._leaf_order(True), device=dev_tables)
             for name in bufs:
                 mine.append((str(b).zfill(z), name, bufs[name], mols[name]))
+        del trees
         timer.end_timing(f"round-{round_idx}")
 
     round_idx += 1
     timer.init_timing(f"round-{round_idx}")
-    everything = ordered(_allgather_tables(mine, dist, tdev))
-    clusters = None
+    ex = _Exchange(dist, tdev, table_dev)
+    final, _ = ex.run(mine, None, lambda b: 0)
+    timer.exchange[f"round-{round_idx}"] = {"sent": ex.bytes_sent, "received": ex.bytes_received}  # type: ignore[attr-defined]
+    del mine
+    result: tp.Any = None
     if rank == 0:
+        everything = final[0][1] if final else []
         tree = _merge_rounds([[(t, idx) for _, _, t, idx in everything]], threshold=threshold + midsection_threshold_change,
                              criterion=final_merge_criterion, **common)[0]
-        clusters = tree.get_cluster_mol_ids()
+        result = tree if return_tree else tree.get_cluster_mol_ids()
         if out_dir is not None:
             _write_outputs(Path(out_dir), tree, save_centroids)
     dist.barrier()
     timer.end_timing(f"round-{round_idx}")
     timer.end_timing("total")
-    return clusters, timer
+    return result, timer

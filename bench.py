@@ -1,22 +1,23 @@
 #!/usr/bin/env python3
 r"""Benchmark of the BitBIRCH insertion hot path on MI355X.
 
-One "step" = one pass of the hot path over one batch: `BitBirch.fit` of the whole
-synthetic workload (BASELINE.json configs[1]: 1 M synthetic 2048-bit packed fingerprints,
-threshold 0.3, branching factor 50, diameter merge) into a fresh HBM-resident tree, with
-the fingerprints already resident in HBM when the timed region starts.
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--n-fps M] [--workload fake|ecfp|rdkit]
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--n-fps M]
+N = 1 (BASELINE.json configs[1]): one "step" = `BitBirch.fit` of the whole synthetic workload (1 M synthetic
+2048-bit packed fingerprints, threshold 0.3, branching factor 50, diameter merge) into a fresh HBM-resident
+tree, fingerprints already resident in HBM when the timed region starts.
 
-For N > 1 (launched by torch.distributed.run, one rank per GPU) every rank clusters its own
-shard of the same size - the data-parallel first round of the reference's multiround scheme
-(multiround.py:401-422) - with no collective inside the timed region (weak scaling).
+N > 1 (the multiround path of configs[3]/[4]): one rank per GPU over RCCL; one "step" = the WHOLE
+`run_multiround_distributed` job on N shards of M rows each (one shard per GPU, resident in HBM): round 1
+(fit + full refinement per shard, no collective), the RCCL exchange of the leaf BitFeature tables to the
+merging ranks, the merge round, the exchange to rank 0, the final sequential merge and the cluster labels.
+Weak scaling: the per-GPU shard is fixed as N grows.  When WORLD_SIZE is not set, `--gpus N` re-executes
+itself under `python -m torch.distributed.run` with N ranks; when it is set it must equal N.
 
-Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (the tree insertion
-kernel; algorithmic bytes = 264 B per clustered fingerprint) timed
-with HIP events on its launch stream inside libbbhip; `k1_roofline` is the arr-vec Tanimoto
-kernel (264 B per row) that the north star's HBM target refers to.  `cpu_baseline` is the
-CPU oracle (a C restatement of the reference path, kind "port") on a bounded sample.
+Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (the tree insertion kernel;
+algorithmic bytes = 264 B per inserted element) timed with HIP events on its launch
+stream inside libbbhip; `k1_roofline` is the arr-vec Tanimoto kernel (264 B per row) that the north star's
+HBM target refers to.  `cpu_baseline` is the CPU oracle (a C restatement of the reference path, kind "port").
 """
 from __future__ import annotations
 
@@ -24,6 +25,8 @@ import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -34,6 +37,7 @@ sys.path.insert(0, str(REPO / "tests"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 BYTES_PER_FP = 264  # 256 B row read once + 8 B label
+_W8 = [128, 64, 32, 16, 8, 4, 2, 1]
 
 
 def synth_fake_fps(n: int, seed: int, device):
@@ -44,7 +48,7 @@ def synth_fake_fps(n: int, seed: int, device):
 
     g = torch.Generator(device=device).manual_seed(seed)
     out = torch.empty((n, 256), dtype=torch.uint8, device=device)
-    weights = torch.tensor([128, 64, 32, 16, 8, 4, 2, 1], dtype=torch.int32, device=device)
+    weights = torch.tensor(_W8, dtype=torch.int32, device=device)
     chunk = 50_000
     for lo in range(0, n, chunk):
         m = min(chunk, n - lo)
@@ -64,14 +68,73 @@ def synth_fake_fps(n: int, seed: int, device):
     return out
 
 
-def cpu_baseline(fps_host, bf: int, thr: float, sample: int) -> dict:
+def _synth_planted(n: int, seed: int, device, pop_mean: float, pop_std: float, pop_lo: float, pop_hi: float,
+                   noise: float, n_features: int = 2048):
+    r"""Rows scattered around n/50 planted prototypes: `noise` of a prototype's bits dropped and as many
+    random bits added (the distribution of tests/golden/cases.py sparse_ecfp_like / dense_rdkit_like)."""
+    import torch
+
+    g = torch.Generator(device=device).manual_seed(seed)
+    k = max(n // 50, 1)
+    pops = torch.clamp(torch.round(torch.randn(k, device=device, generator=g) * pop_std + pop_mean), pop_lo, pop_hi).to(torch.int64)
+    weights = torch.tensor(_W8, dtype=torch.int32, device=device)
+    protos = torch.empty((k, n_features // 8), dtype=torch.uint8, device=device)
+    chunk = 50_000
+    for lo in range(0, k, chunk):
+        m = min(chunk, k - lo)
+        ranks = torch.rand((m, n_features), device=device, generator=g).argsort(dim=1).argsort(dim=1)
+        bits = (ranks < pops[lo:lo + m, None]).to(torch.int32)
+        protos[lo:lo + m] = (bits.view(m, -1, 8) * weights).sum(dim=2).to(torch.uint8)
+    out = torch.empty((n, n_features // 8), dtype=torch.uint8, device=device)
+    shifts = torch.arange(7, -1, -1, device=device, dtype=torch.uint8)
+    for lo in range(0, n, chunk):
+        m = min(chunk, n - lo)
+        which = torch.randint(0, k, (m,), device=device, generator=g)
+        pb = ((protos[which][:, :, None] >> shifts) & 1).bool().view(m, n_features)
+        keep = torch.rand((m, n_features), device=device, generator=g) > noise
+        add = torch.rand((m, n_features), device=device, generator=g) < (noise * pops[which].double() / n_features)[:, None]
+        bits = ((pb & keep) | add).to(torch.int32)
+        out[lo:lo + m] = (bits.view(m, -1, 8) * weights).sum(dim=2).to(torch.uint8)
+    return out
+
+
+def synth_ecfp(n: int, seed: int, device, n_features: int = 2048):
+    r"""S-ecfp: sparse ECFP4-like rows, popcount ~ N(48, 12) clipped to [8, 160]."""
+    return _synth_planted(n, seed, device, 48.0, 12.0, 8, 160, 0.15, n_features)
+
+
+def synth_rdkit_like(n: int, seed: int, device, n_features: int = 2048):
+    r"""S-rdkit-like (BASELINE configs[4]): dense rows, popcount ~ N(900, 250) clipped."""
+    return _synth_planted(n, seed, device, 900.0, 250.0, 64, 1900, 0.12, n_features)
+
+
+WORKLOADS = {
+    # name: (generator, threshold, description)
+    "fake": (synth_fake_fps, 0.3, "make_fake_fingerprints popcount distribution"),
+    "ecfp": (synth_ecfp, 0.3, "S-ecfp sparse ECFP4-like rows around n/50 planted prototypes"),
+    "rdkit": (synth_rdkit_like, 0.6, "S-rdkit-like dense rows (popcount ~N(900,250)) around n/50 planted prototypes"),
+}
+
+
+def _cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(fps_host, bf: int, thr: float) -> dict:
     from oracle_engine import OracleEngine
 
     import numpy as np
 
+    sample = fps_host.shape[0]
     eng = OracleEngine(bf, thr, 0, 0.0, np.zeros(0), 2048)
     t0 = time.perf_counter()
-    eng.fit_packed(fps_host[:sample])
+    eng.fit_packed(fps_host)
     dt = time.perf_counter() - t0
     eng.close()
     return {
@@ -79,57 +142,170 @@ def cpu_baseline(fps_host, bf: int, thr: float, sample: int) -> dict:
         "unit": "fingerprints/s",
         "cores": 1,
         "kind": "port",
-        "sample": f"oracle (C restatement of the reference path) fit of the first {sample} "
-                  f"fingerprints of the same workload, {dt:.1f} s on one host core",
+        "cpu_model": _cpu_model(),
+        "nproc": os.cpu_count(),
+        "sample": f"oracle (C restatement of the reference path; the algorithm is sequential: 1 thread) fit of "
+                  f"{sample} fingerprints of the same workload, {dt:.1f} s on one host core",
     }
 
 
-def main() -> None:
+def _cpu_round1(args_):
+    r"""One shard of the CPU multiround baseline's first round (fit + full refinement), in a pool worker."""
+    path, start, end, bf, thr = args_
+    import numpy as np
+    from oracle_engine import OracleEngine
+
+    from bblean_amd import BitBirch
+
+    t = BitBirch(branching_factor=bf, threshold=thr, merge_criterion="diameter", _engine_factory=OracleEngine)
+    t.fit(Path(path), reinsert_indices=range(start, end))
+    t.delete_internal_nodes()
+    bufs, mols = t._refine_tables(Path(path), initial_mol=start)
+    t.reset()
+    t.set_merge("tolerance-diameter", tolerance=0.05, threshold=thr)
+    for name in bufs:
+        t._fit_buffers(bufs[name], mols[name])
+    t.delete_internal_nodes()
+    bufs, mols = t._bf_tables(t._leaf_order(True))
+    return {k: np.asarray(v) for k, v in bufs.items()}, {k: (v.counts, v.flat) for k, v in mols.items()}
+
+
+def cpu_multiround_baseline(files: list[Path], bf: int, thr: float, bin_size: int = 10) -> dict:
+    r"""the N-process multiround CPU baseline - round 1 in a process pool of
+    min(shards, host cores) workers (the reference's `mp.Pool`, multiround.py:419-422), merge rounds in one
+    process each like the reference; the C oracle engine under this repo's host logic."""
+    import multiprocessing as mp
+
+    import numpy as np
+    from oracle_engine import OracleEngine
+
+    from bblean_amd.bitbirch import _IndexLists
+    from bblean_amd.multiround import _files_range_tuples, _merge_rounds
+    from bblean_amd.utils import batched
+
+    infos = _files_range_tuples(files)
+    nproc = max(1, min(len(files), os.cpu_count() or 1))
+    t0 = time.perf_counter()
+    with mp.get_context("fork").Pool(nproc) as pool:
+        r1 = pool.map(_cpu_round1, [(str(f), s, e, bf, thr) for _, f, s, e in infos])
+    t1 = time.perf_counter()
+    entries = []
+    for (lab, _, _, _), (bufs, mols) in zip(infos, r1):
+        for name in bufs:
+            entries.append((f"label-{lab}-{name.replace('8', '08')}", name, bufs[name], _IndexLists(*mols[name])))
+    entries.sort(key=lambda e: e[0])
+    common = dict(branching_factor=bf, tolerance=0.05, engine_factory=OracleEngine, device=0, threshold=thr,
+                  criterion="tolerance-diameter")
+    batches = [sorted(b, key=lambda e: int(e[1][4:]), reverse=True) for b in batched(entries, bin_size)]
+    trees = _merge_rounds([[(t, i) for _, _, t, i in b] for b in batches], **common)
+    z = len(str(len(batches)))
+    entries = []
+    for b, tree in enumerate(trees):
+        bufs, mols = tree._bf_tables(tree._leaf_order(True))
+        for name in bufs:
+            entries.append((f"label-{str(b).zfill(z)}-{name.replace('8', '08')}", name, bufs[name], mols[name]))
+    entries.sort(key=lambda e: e[0])
+    t2 = time.perf_counter()
+    final = _merge_rounds([[(t, i) for _, _, t, i in entries]], **common)[0]
+    k = len(final._leaves()["ids"])
+    t3 = time.perf_counter()
+    rows = infos[-1][3]
+    return {"value": rows / (t3 - t0), "unit": "fingerprints/s", "kind": "port", "cores": nproc, "nproc": os.cpu_count(),
+            "cpu_model": _cpu_model(), "rows": rows, "files": len(files), "clusters": k,
+            "rounds_s": {"round-1": round(t1 - t0, 3), "round-2": round(t2 - t1, 3), "round-3": round(t3 - t2, 3)},
+            "sample": f"{rows} rows of the same workload in {len(files)} shard files; round 1 in {nproc} processes, "
+                      "merge rounds sequential (one process per tree, as in the reference)"}
+
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _profile(lib, name: bytes) -> tuple[int, float, int]:
+    launches, total_ms, units = C.c_int64(0), C.c_double(0.0), C.c_int64(0)
+    lib.bbh_profile_get(name, C.byref(launches), C.byref(total_ms))
+    lib.bbh_profile_units(name, C.byref(units))
+    return int(launches.value), float(total_ms.value), int(units.value)
+
+
+def parse() -> argparse.Namespace:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n-fps", type=int, default=1_000_000)
+    ap.add_argument("--n-fps", type=int, default=None,
+                    help="rows per GPU (default 1 000 000 at N=1, 250 000 per GPU at N>1)")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="fake")
     ap.add_argument("--bf", type=int, default=50)
-    ap.add_argument("--threshold", type=float, default=0.3)
-    ap.add_argument("--cpu-sample", type=int, default=300_000)
+    ap.add_argument("--threshold", type=float, default=None)
+    ap.add_argument("--cpu-sample", type=int, default=None, help="rows of the CPU baseline (default: all)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--k1-rows", type=int, default=8_000_000)
     ap.add_argument("--shards", type=int, default=512)
     ap.add_argument("--multiround-files", type=int, default=64, help="0 skips the file-based multiround run")
-    args = ap.parse_args()
+    return ap.parse_args()
 
-    import numpy as np
+
+def main() -> None:
+    args = parse()
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        # `python bench.py --gpus N` run bare: N ranks of this same script, one per GPU
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(Path(__file__).resolve())] + sys.argv[1:]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        sys.exit(subprocess.run(cmd, env=env).returncode)
+    world = int(env_world or "1")
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                 f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...)")
+    if args.threshold is None:
+        args.threshold = WORKLOADS[args.workload][1]
+    if args.n_fps is None:
+        args.n_fps = 1_000_000 if world == 1 else 250_000
+    if world == 1:
+        single_gpu(args)
+    else:
+        multi_gpu(args, world)
+
+
+# ------------------------------------------------------------------------------------------------------
+def multi_gpu(args: argparse.Namespace, world: int) -> None:
     import torch
+    import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist  # type: ignore[no-redef]
+    dist.init_process_group("nccl", device_id=dev)
 
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
-
-    from bblean_amd import BitBirch, _lib
+    from bblean_amd import _lib
+    from bblean_amd.multiround import ShardRows, run_multiround_distributed
 
     lib = _lib.load()
     n = args.n_fps
-    fps = synth_fake_fps(n, seed=1000 + rank, device=dev)  # resident in HBM
+    gen = WORKLOADS[args.workload][0]
+    shard = gen(n, 1000 + rank, dev)  # this rank's shard, resident in HBM
     torch.cuda.synchronize()
+    inputs = [ShardRows(n) for _ in range(world)]
+    inputs[rank] = shard
 
-    def one_step() -> BitBirch:
-        tree = BitBirch(branching_factor=args.bf, threshold=args.threshold, merge_criterion="diameter",
-                        device=local_rank)
-        tree.fit(fps)
-        return tree
+    state: dict = {}
+
+    def one_step() -> None:
+        tree, timer = run_multiround_distributed(inputs, None, branching_factor=args.bf, threshold=args.threshold,
+                                                 device=local_rank, return_tree=True)
+        if tree is not None:  # rank 0: the labels are part of "clustered"
+            state["labels"] = tree.get_assignments()
+            state["clusters"] = len(tree._leaves()["ids"])
+        state["timer"] = timer
 
     def barrier() -> None:
-        if dist is not None:
-            dist.barrier()
+        dist.barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -138,23 +314,125 @@ def main() -> None:
     lib.bbh_profile_reset()
     barrier()
     t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    launches, total_ms, units = _profile(lib, b"tree_insert")
+    lib.bbh_profile_enable(0)
+    timer = state["timer"]
+    # per-round maxima over the ranks and the bytes every rank put on / took off the links (last step)
+    names = sorted(k for k in timer.timings if k != "total")
+    tt = torch.tensor([timer.timings[k] for k in names] + [timer.timings["total"]], dtype=torch.float64, device=dev)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    ex = torch.tensor([[timer.exchange.get(k, {}).get("sent", 0), timer.exchange.get(k, {}).get("received", 0)] for k in names],
+                      dtype=torch.int64, device=dev)
+    ex_all = [torch.zeros_like(ex) for _ in range(world)]
+    dist.all_gather(ex_all, ex)
+    if rank == 0:
+        avg_ms = total_ms / max(launches, 1)
+        achieved = BYTES_PER_FP * (units / max(launches, 1)) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        labels = state.get("labels")
+        out = {
+            "metric": "fingerprints/sec clustered (2048-bit, thr=%.2g)" % args.threshold,
+            "value": world * args.steps * n / elapsed,
+            "unit": "fingerprints/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8",
+            "data": "synthetic",
+            "config": {
+                "workload": f"multiround over {world} GPUs: {world} shards x {n} synthetic 2048-bit packed fingerprints "
+                            f"({WORKLOADS[args.workload][2]}), one shard per GPU resident in HBM, threshold={args.threshold}, "
+                            f"branching_factor={args.bf}, reference defaults otherwise (diameter, full refinement, one merge "
+                            "round in bins of 10, tolerance-diameter merges); timed region = run_multiround_distributed "
+                            "(round 1, RCCL exchange of the BitFeature tables to the merging ranks, merge round, exchange to "
+                            "rank 0, final merge) + cluster labels",
+                "clusters": state.get("clusters"),
+                "labelled": None if labels is None else int(labels.size),
+                "rccl_ranks": dist.get_world_size(),
+                "backend": dist.get_backend(),
+                "rounds_s_max_over_ranks": {k: round(float(v), 4) for k, v in zip(names + ["total"], tt.tolist())},
+                "exchange_bytes_per_rank": {k: {"sent": [int(e[i, 0]) for e in ex_all], "received": [int(e[i, 1]) for e in ex_all]}
+                                            for i, k in enumerate(names) if k != "round-1"},
+            },
+            "roofline": {
+                "kernel": "k_tree_fast / k_tree_insert on rank 0 (all launches of the timed steps)",
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "launches": launches,
+                "avg_launch_ms": avg_ms,
+                "elements_per_launch": units / max(launches, 1),
+                "note": "latency/dependency-bound sequential insertion; 264 algorithmic bytes per inserted element",
+            },
+            "cpu_baseline": None,
+        }
+        print(json.dumps(out), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------------------
+def single_gpu(args: argparse.Namespace) -> None:
+    import numpy as np
+    import torch
+
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from bblean_amd import BitBirch, _lib
+
+    lib = _lib.load()
+    n = args.n_fps
+    gen = WORKLOADS[args.workload][0]
+    fps = gen(n, 1000, dev)  # resident in HBM
+    torch.cuda.synchronize()
+
+    def one_step() -> BitBirch:
+        tree = BitBirch(branching_factor=args.bf, threshold=args.threshold, merge_criterion="diameter",
+                        device=local_rank)
+        tree.fit(fps)
+        return tree
+
+    for _ in range(args.warmup):
+        one_step()
+    lib.bbh_profile_enable(1)
+    lib.bbh_profile_reset()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
     tree = None
     for _ in range(args.steps):
         tree = one_step()
-    barrier()
+    torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
 
-    launches, total_ms = C.c_int64(0), C.c_double(0.0)
-    lib.bbh_profile_get(b"tree_insert", C.byref(launches), C.byref(total_ms))
+    k_launches, total_ms, units = _profile(lib, b"tree_insert")
     lib.bbh_profile_enable(0)
-    k_launches = max(int(launches.value), 1)
-    avg_ms = total_ms.value / k_launches
-    fps_per_launch = args.steps * n / k_launches
-    achieved = BYTES_PER_FP * fps_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    k_launches = max(k_launches, 1)
+    avg_ms = total_ms / k_launches
+    achieved = BYTES_PER_FP * (units / k_launches) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+
+    # fit + labels: the labels (get_assignments, reference bitbirch.py:1002-1047) on top of the timed fit
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    t_e2e = one_step()
+    labels = t_e2e.get_assignments()
+    e2e = time.perf_counter() - t1
+    n_clusters = int(labels.max())
+    del t_e2e
 
     # K1 (arr-vec Tanimoto): the HBM-bound kernel, on an array larger than the 256 MiB
     # Infinity Cache so that the rate is an HBM rate (the 1 M-row workload itself is 256 MB)
@@ -228,7 +506,8 @@ def main() -> None:
     # the same rows as shard files; all shards of round 1 and all batches of the merge round share
     # kernel launches, the final merge is one sequential tree
     mr_stats = None
-    if args.multiround_files > 1 and rank == 0:
+    cpu_mr = None
+    if args.multiround_files > 1:
         import tempfile
 
         from bblean_amd.multiround import run_multiround_bitbirch
@@ -247,11 +526,14 @@ def main() -> None:
             timer = run_multiround_bitbirch(names, out_dir, branching_factor=args.bf, threshold=args.threshold,
                                             num_initial_processes=1, device=local_rank)
             dt = time.perf_counter() - t1
-        mr_stats = {"files": args.multiround_files, "rows": per * args.multiround_files, "seconds": dt,
-                    "fingerprints_per_s": per * args.multiround_files / dt,
-                    "rounds_s": {k: round(v, 3) for k, v in timer.timings.items()},
-                    "note": "file-compatible multiround with the reference's defaults (full refinement, one merge "
-                            "round in bins of 10, tolerance-diameter merges); files on tmpfs/disk inside the timing"}
+            mr_stats = {"files": args.multiround_files, "rows": per * args.multiround_files, "seconds": dt,
+                        "fingerprints_per_s": per * args.multiround_files / dt,
+                        "rounds_s": {k: round(v, 3) for k, v in timer.timings.items()},
+                        "note": "file-compatible multiround with the reference's defaults (full refinement, one merge "
+                                "round in bins of 10, tolerance-diameter merges); files on tmpfs/disk inside the timing"}
+            if not args.no_cpu:
+                # bounded: a quarter of the files (same rows per file) so that the default run stays within minutes
+                cpu_mr = cpu_multiround_baseline(names[: max(2, args.multiround_files // 4)], args.bf, args.threshold)
         del host
 
     traffic = None
@@ -264,71 +546,71 @@ def main() -> None:
                 traffic = (2.0 * rec["tree_fetch_kb_total"] + rec["tree_write_kb_total"]) * 1024.0 / max(rec["tree_launches"], 1)
         except Exception:
             traffic = None
-    if rank == 0:
-        n_clusters = len(tree._leaves()["ids"]) if tree is not None else 0
-        out = {
-            "metric": "fingerprints/sec clustered (2048-bit, thr=0.3)",
-            "value": world * args.steps * n / elapsed,
-            "unit": "fingerprints/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "u8",
-            "data": "synthetic",
-            "config": {
-                "workload": f"{n} synthetic 2048-bit packed fingerprints per GPU (make_fake_fingerprints "
-                            f"popcount distribution), threshold={args.threshold}, branching_factor={args.bf}, "
-                            "merge=diameter, BitBirch.fit into a fresh HBM-resident tree, inputs resident in HBM",
-                "clusters": n_clusters,
-                "multi_gpu": "independent shard per GPU (multiround round 1), no collective in the timed region",
-            },
-            "roofline": {
-                "kernel": "k_tree_insert",
-                "bound": "hbm",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic,
-                "launches": k_launches,
-                "avg_launch_ms": avg_ms,
-                "note": "latency/dependency-bound sequential insertion; 264 algorithmic bytes per fingerprint",
-            },
-            "k1_roofline": {
-                "kernel": "k_arr_vec<16,true> (arr-vec Tanimoto, 264 B/row)",
-                "bound": "hbm",
-                "achieved": k1_gbs,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": k1_gbs / HBM_PEAK_GBS,
-                "rows": k1_rows,
-                "avg_launch_ms": k1_ms,
-            },
-            "k2_valu": {
-                "kernel": "k_best_match<64> (batched node compare, exact first-argmax)",
-                "bound": "valu",
-                "achieved": k2_laneops / 1e12,
-                "peak": k2_peak / 1e12,
-                "unit": "T lane-ops/s",
-                "frac": k2_laneops / k2_peak,
-                "queries": nq2, "centroids": nc2, "avg_launch_ms": k2_ms,
-            },
-            "concurrent_shards": shard_stats,
-            "multiround_one_gpu": mr_stats,
-        }
-        if not args.no_cpu and world == 1:
-            sample = min(args.cpu_sample, n)
-            out["cpu_baseline"] = cpu_baseline(fps[:sample].cpu().numpy(), args.bf, args.threshold, sample)
-        else:
-            out["cpu_baseline"] = None
-        print(json.dumps(out))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    out = {
+        "metric": "fingerprints/sec clustered (2048-bit, thr=%.2g)" % args.threshold,
+        "value": args.steps * n / elapsed,
+        "unit": "fingerprints/s",
+        "n_gpus": 1,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u8",
+        "data": "synthetic",
+        "config": {
+            "workload": f"{n} synthetic 2048-bit packed fingerprints ({WORKLOADS[args.workload][2]}), "
+                        f"threshold={args.threshold}, branching_factor={args.bf}, "
+                        "merge=diameter, BitBirch.fit into a fresh HBM-resident tree, inputs resident in HBM",
+            "clusters": n_clusters,
+        },
+        "roofline": {
+            "kernel": "k_tree_fast (the tree insertion kernel)",
+            "bound": "hbm",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic,
+            "launches": k_launches,
+            "avg_launch_ms": avg_ms,
+            "elements_per_launch": units / k_launches,
+            "note": "latency/dependency-bound sequential insertion; 264 algorithmic bytes per fingerprint",
+        },
+        "end_to_end": {
+            "seconds": e2e, "fingerprints_per_s": n / e2e,
+            "note": "one extra step: BitBirch.fit + get_assignments() (leaf export, member lists, labels 1..K)",
+        },
+        "k1_roofline": {
+            "kernel": "k_arr_vec<16,true> (arr-vec Tanimoto, 264 B/row)",
+            "bound": "hbm",
+            "achieved": k1_gbs,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": k1_gbs / HBM_PEAK_GBS,
+            "rows": k1_rows,
+            "avg_launch_ms": k1_ms,
+        },
+        "k2_valu": {
+            "kernel": "k_best_match<64> (batched node compare, exact first-argmax)",
+            "bound": "valu",
+            "achieved": k2_laneops / 1e12,
+            "peak": k2_peak / 1e12,
+            "unit": "T lane-ops/s",
+            "frac": k2_laneops / k2_peak,
+            "queries": nq2, "centroids": nc2, "avg_launch_ms": k2_ms,
+        },
+        "concurrent_shards": shard_stats,
+        "multiround_one_gpu": mr_stats,
+        "cpu_multiround_baseline": cpu_mr,
+    }
+    if not args.no_cpu:
+        sample = n if args.cpu_sample is None else min(args.cpu_sample, n)
+        out["cpu_baseline"] = cpu_baseline(fps[:sample].cpu().numpy(), args.bf, args.threshold)
+    else:
+        out["cpu_baseline"] = None
+    print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -86,6 +86,10 @@ int bbh_jt_best_match(const uint8_t* queries, int64_t nq, const uint8_t* cents, 
 int bbh_unpack(const uint8_t* packed, int64_t n, int64_t nbytes, int64_t n_features,
                uint8_t* out, void* stream);
 
+/* pack_fingerprints (fingerprints.py:46-49 = np.packbits(axis=-1), MSB first): n x n_features uint8
+ * of 0/non-0 -> n x ceil(n_features/8) packed uint8, the last byte zero-padded. */
+int bbh_pack(const uint8_t* unpacked, int64_t n, int64_t n_features, uint8_t* out, void* stream);
+
 /* add_rows (similarity.cpp:381-400): column sums of an n x n_features uint8 array,
  * or, with packed != 0, of the unpacked view of an n x nbytes packed array
  * (jt_isim_packed_u8's inner step, :407-411).  out: n_features uint64. */
@@ -193,6 +197,8 @@ int bbh_tree_stats(bbh_tree* t, uint64_t* out8);
 int bbh_profile_enable(int on);
 int bbh_profile_reset(void);
 int bbh_profile_get(const char* name, int64_t* launches, double* total_ms);
+/* work units (rows / inserted elements) summed over the recorded launches of `name` */
+int bbh_profile_units(const char* name, int64_t* units);
 
 #ifdef __cplusplus
 }

@@ -24,13 +24,45 @@ def sparse_ecfp_like(n: int, n_features: int, seed: int) -> np.ndarray:
     return np.packbits(bits.astype(np.uint8), axis=1)
 
 
+def dense_rdkit_like(n: int, n_features: int, seed: int) -> np.ndarray:
+    r"""S-rdkit-like (BASELINE config 5): dense path-fingerprint-like rows, popcount
+    ~ N(900, 250) clipped to [64, 1900] (scaled with the width), scattered around n/50 planted prototypes
+    (12 % of a prototype's bits dropped, as many random bits added) so that threshold 0.6 with the
+    diameter criterion gives non-trivial clusters.  Packed uint8."""
+    rng = np.random.default_rng(seed)
+    k = max(n // 50, 1)
+    scale = n_features / 2048.0
+    pops = np.clip(np.rint(rng.normal(900 * scale, 250 * scale, k)), 64 * scale, 1900 * scale).astype(np.int64)
+    protos = rng.random((k, n_features)).argsort(axis=1) < pops[:, None]
+    out = np.empty((n, n_features // 8), dtype=np.uint8)
+    for lo in range(0, n, 20_000):  # chunks: n x n_features booleans would not fit for big n
+        m = min(20_000, n - lo)
+        which = rng.integers(0, k, m)
+        keep = rng.random((m, n_features)) > 0.12
+        add = rng.random((m, n_features)) < (0.12 * pops[which] / n_features)[:, None]
+        out[lo:lo + m] = np.packbits(((protos[which] & keep) | add).astype(np.uint8), axis=1)
+    return out
+
+
+def fake_chunks(n: int, seed0: int, make_fake, n_features: int = 2048) -> np.ndarray:
+    r"""S-fake(N, seed): chunk c of 100 000 rows = make_fake_fingerprints(100_000, seed=seed0 + c)
+    (the 1 M-row array of BASELINE.md section 2 is fake_chunks(1_000_000, 1000))."""
+    parts = [make_fake(min(100_000, n - lo), n_features=n_features, seed=seed0 + c, pack=True)
+             for c, lo in enumerate(range(0, n, 100_000))]
+    return np.concatenate(parts) if len(parts) > 1 else parts[0]
+
+
 def make_input(case: dict, make_fake) -> np.ndarray:
     kind = case.get("kind", "fake")
     n, nf = case["n"], case["n_features"]
     if kind == "fake":
         return make_fake(n, n_features=nf, seed=case["seed"], pack=True)
+    if kind == "fake_chunks":
+        return fake_chunks(n, case["seed"], make_fake, nf)
     if kind == "sparse":
         return sparse_ecfp_like(n, nf, case["seed"])
+    if kind == "rdkit":
+        return dense_rdkit_like(n, nf, case["seed"])
     if kind == "zeros":
         return np.zeros((n, nf // 8), dtype=np.uint8)
     if kind == "ones":
@@ -100,6 +132,41 @@ MULTIROUND_CASES = [
     dict(name="mr_none_big", seeds=[301, 302, 303], n_per_file=1500,
          kwargs=dict(bin_size=10, threshold=0.2, branching_factor=50, refinement_before_midsection="none")),
 ]
+
+
+# Runs of the REFERENCE at sizes whose trees are 4-5 levels deep: only digests
+# are committed (tests/golden/scale.json, written by make_golden_scale.py).  `gpu_only`: too slow for the
+# CPU suite's oracle leg, checked on the HIP engine (and by the oracle when BB_SCALE_ORACLE=1).
+_REFINE_TD = {"set_merge": {"criterion": "tolerance-diameter", "tolerance": 0.05}}
+SCALE_CASES = [
+    _c("fake_200k", 200_000, 50, 0.3, "diameter", seed=1000, kind="fake_chunks", refine=_REFINE_TD),
+    _c("fake_bf254_100k", 100_000, 254, 0.3, "diameter", seed=1000, kind="fake_chunks"),
+    _c("fake_bf1000_100k", 100_000, 1000, 0.3, "diameter", seed=1000, kind="fake_chunks"),
+    _c("ecfp_100k", 100_000, 50, 0.3, "diameter", seed=2024, kind="sparse", refine=_REFINE_TD),
+    _c("ecfp_bf254_100k", 100_000, 254, 0.3, "diameter", seed=2025, kind="sparse"),
+    _c("rdkit_100k", 100_000, 50, 0.6, "diameter", seed=2026, kind="rdkit"),
+    _c("rdkit_bf254_100k", 100_000, 254, 0.6, "diameter", seed=2027, kind="rdkit"),
+    _c("fake_1M", 1_000_000, 50, 0.3, "diameter", seed=1000, kind="fake_chunks", gpu_only=True),
+]
+
+# BASELINE configs 4 and 5 at test scale: 8 shard files through multiround with the CLI defaults
+# (bf 254, full refinement, one merge round in bins of 10, tolerance-diameter merges), intermediate
+# round-* tables kept (cleanup=False) and digested file by file.
+MULTIROUND_SCALE_CASES = [
+    dict(name="mr_cfg4_ecfp_8x25k", kind="sparse", seeds=list(range(4000, 4008)), n_per_file=25_000,
+         kwargs=dict(threshold=0.3)),
+    dict(name="mr_cfg5_rdkit_8x25k", kind="rdkit", seeds=list(range(5000, 5008)), n_per_file=25_000,
+         kwargs=dict(threshold=0.6, initial_merge_criterion="diameter")),
+    dict(name="mr_fake_bf50_8x25k", kind="fake", seeds=list(range(6000, 6008)), n_per_file=25_000,
+         kwargs=dict(threshold=0.3, branching_factor=50)),
+]
+
+
+def multiround_shard(case: dict, seed: int, make_fake) -> np.ndarray:
+    kind = case.get("kind", "fake")
+    if kind == "fake":
+        return make_fake(case["n_per_file"], seed=seed)
+    return make_input(dict(kind=kind, n=case["n_per_file"], n_features=2048, seed=seed), make_fake)
 
 
 def clustered_dense(n: int, n_features: int, k: int, seed: int, flip: float = 0.08) -> np.ndarray:

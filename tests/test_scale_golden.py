@@ -1,0 +1,120 @@
+r"""Parity at scale against the REFERENCE itself (SURVEY.md section 8c, G6 + G9): digests of reference runs at
+100 k - 1 M rows (4-5-level trees, uint16 tiers, bf 254 and bf 1000 at depth) and of the reference's multiround
+on 8 shard files with every intermediate round-* table kept - BASELINE configs 4 (S-ecfp, thr 0.3) and 5
+(S-rdkit-like, thr 0.6, diameter) at test scale.  CPU tests pin the oracle; `-m gpu` tests run the HIP engine
+through the same host code, file-based and one-rank-per-GPU."""
+from __future__ import annotations
+
+import os
+import pickle
+import socket
+import subprocess
+import sys
+import tempfile
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from cases import MULTIROUND_SCALE_CASES, SCALE_CASES
+from oracle_engine import OracleEngine
+from scale_cases import ALL_MULTIROUND, check_final, run_multiround_files, run_scale_tree, write_shards
+
+REPO = Path(__file__).resolve().parents[1]
+_CPU_TREES = [c for c in SCALE_CASES if not c.get("gpu_only") or os.environ.get("BB_SCALE_ORACLE")]
+
+
+@pytest.mark.parametrize("case", _CPU_TREES, ids=[c["name"] for c in _CPU_TREES])
+def test_oracle_vs_reference_at_scale(case):
+    run_scale_tree(case, OracleEngine)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", SCALE_CASES, ids=[c["name"] for c in SCALE_CASES])
+def test_hip_vs_reference_at_scale(case):
+    run_scale_tree(case, None)
+
+
+@pytest.mark.parametrize("case", ALL_MULTIROUND, ids=[c["name"] for c in ALL_MULTIROUND])
+def test_multiround_round_files_oracle(case, tmp_path):
+    run_multiround_files(case, OracleEngine, tmp_path)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ALL_MULTIROUND, ids=[c["name"] for c in ALL_MULTIROUND])
+def test_multiround_round_files_hip(case, tmp_path):
+    run_multiround_files(case, None, tmp_path)
+
+
+# ---- one rank per GPU --------------------------------------------------------------------------------
+_WORKER = r"""
+import os, sys, pickle
+from pathlib import Path
+sys.path.insert(0, {repo!r}); sys.path.insert(0, {repo!r} + "/tests"); sys.path.insert(0, {repo!r} + "/tests/golden")
+import torch.distributed as dist
+from bblean_amd.multiround import run_multiround_distributed
+engine = None
+if {use_oracle}:
+    from oracle_engine import OracleEngine as engine
+dist.init_process_group({backend!r}, init_method="tcp://127.0.0.1:{port}", rank=int(sys.argv[1]), world_size={world})
+files = sorted(Path({d!r}).glob("fps.*.npy"))
+clusters, timer = run_multiround_distributed(files, Path({d!r}) / "out", _engine_factory=engine, **{kwargs!r})
+if dist.get_rank() == 0:
+    pickle.dump(clusters, open(Path({d!r}) / "clusters_rank0.pkl", "wb"))
+pickle.dump(timer.exchange, open(Path({d!r}) / ("exchange_rank%d.pkl" % dist.get_rank()), "wb"))
+dist.destroy_process_group()
+"""
+
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run_distributed(case: dict, d: Path, *, use_oracle: bool, backend: str, world: int):
+    write_shards(d, case)
+    (d / "out").mkdir()
+    src = _WORKER.format(repo=str(REPO), use_oracle=use_oracle, backend=backend, port=_free_port(), world=world, d=str(d),
+                         kwargs=dict(case["kwargs"]))
+    (d / "worker.py").write_text(src)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, str(d / "worker.py"), str(r)], env=env) for r in range(world)]
+    for p in procs:
+        assert p.wait(timeout=1500) == 0
+    clusters = pickle.load(open(d / "clusters_rank0.pkl", "rb"))
+    cents = pickle.load(open(d / "out" / "cluster-centroids-packed.pkl", "rb"))
+    assert clusters == pickle.load(open(d / "out" / "clusters.pkl", "rb"))
+    check_final(case, clusters, cents)
+    return [pickle.load(open(d / f"exchange_rank{r}.pkl", "rb")) for r in range(world)]
+
+
+@pytest.mark.parametrize("case", MULTIROUND_SCALE_CASES[:2], ids=[c["name"] for c in MULTIROUND_SCALE_CASES[:2]])
+def test_configs_4_5_distributed_gloo_world2_oracle(case, tmp_path):
+    r"""BASELINE configs 4 / 5 at test scale through the one-rank-per-GPU path (2 gloo ranks, oracle engine): the
+    point-to-point exchange must reproduce the reference's clusters."""
+    ex = _run_distributed(case, tmp_path, use_oracle=True, backend="gloo", world=2)
+    # every table travels at most once per round, and only towards the rank that merges it
+    for r, per_round in enumerate(ex):
+        for rnd, b in per_round.items():
+            assert b["sent"] >= 0 and b["received"] >= 0
+    assert sum(b["sent"] for per in ex for b in per.values()) == sum(b["received"] for per in ex for b in per.values())
+    assert ex[1]["round-3"]["received"] == 0  # the final merge happens on rank 0 only
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", MULTIROUND_SCALE_CASES[:2], ids=[c["name"] for c in MULTIROUND_SCALE_CASES[:2]])
+def test_configs_4_5_distributed_rccl_world1_hip(case, tmp_path):
+    r"""The same on the real stack: HIP engine, torch.distributed "nccl" (= RCCL), BitFeature tables resident in
+    HBM from the gather kernel to the next round's insertion kernel."""
+    _run_distributed(case, tmp_path, use_oracle=False, backend="nccl", world=1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", MULTIROUND_SCALE_CASES[:2], ids=[c["name"] for c in MULTIROUND_SCALE_CASES[:2]])
+def test_configs_4_5_distributed_world2_hip_device_tables(case, tmp_path):
+    r"""Two ranks with the HIP engine on the one GPU of the box (RCCL refuses two ranks per device, so the wire is
+    gloo): tables are gathered into HBM, handed to the exchange as tensors and inserted from HBM by the receiving
+    rank - no NumPy table on the way."""
+    ex = _run_distributed(case, tmp_path, use_oracle=False, backend="gloo", world=2)
+    assert sum(b["sent"] for per in ex for b in per.values()) > 0
