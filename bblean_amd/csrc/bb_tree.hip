@@ -1308,11 +1308,13 @@ __device__ __forceinline__ void update_tracker_slow(const KCt& k, const Elem& el
     }
 }
 
-// one tree per workgroup
-template <bool PROF, bool SUB, class KCt>
+// one tree per workgroup.  ONE: the cold path of the fast kernel (bb_tree_fast.inc) - insert exactly element
+// `e_first` of tree `trees`; allocation counters and statistics live in LDS (o.ctr / o.stats) across calls, the
+// stop reason and the number of processed elements are returned through o.ctr[8] / o.ctr[9].
+template <bool PROF, bool SUB, class KCt, bool ONE = false>
 __device__ __forceinline__ void tree_insert_body(unsigned char* smem_raw, TreeDev* trees, const uint32_t* gate_nodes,
-                                                 const uint32_t* gate_off, const uint32_t* gate_elems) {
-    TreeDev* T = SUB ? trees : trees + blockIdx.x;
+                                                 const uint32_t* gate_off, const uint32_t* gate_elems, long long e_first = 0) {
+    TreeDev* T = (SUB || ONE) ? trees : trees + blockIdx.x;
     uint32_t* gctr = T->ctr;
     KCt k;
     k.cent = T->node_cent; k.card = T->node_card; k.link = T->node_link; k.rm = T->node_rm; k.hdr = T->node_hdr;
@@ -1348,10 +1350,17 @@ __device__ __forceinline__ void tree_insert_body(unsigned char* smem_raw, TreeDe
     LA u32x4_t* sx = lds<u32x4_t>(k.L, k.o.x);
     int red_slot = 0, cmp_par = 0;
     // allocation counters and tree roots: wave-uniform registers, updated identically by every thread
-    uint32_t cN = uni(T->ctr[C_NODES]), cI = uni(T->ctr[C_IDS]), c8 = uni(T->ctr[C_N8]), c16 = uni(T->ctr[C_N16]);
-    uint32_t c32 = uni(T->ctr[C_N32]), cRoot = SUB ? uni(gate_nodes[blockIdx.x]) : uni(T->ctr[C_ROOT]), cFirst = uni(T->ctr[C_FIRST_LEAF]);
-    uint32_t cDepth = uni(T->ctr[C_DEPTH]);
-    if (tid < 8) stats[tid] = SUB ? 0ull : T->stats[tid];
+    uint32_t cN, cI, c8, c16, c32, cRoot, cFirst, cDepth;
+    if constexpr (ONE) {
+        LA uint32_t* lc = lds<uint32_t>(k.L, k.o.ctr);
+        cN = uni(lc[C_NODES]); cI = uni(lc[C_IDS]); c8 = uni(lc[C_N8]); c16 = uni(lc[C_N16]);
+        c32 = uni(lc[C_N32]); cRoot = uni(lc[C_ROOT]); cFirst = uni(lc[C_FIRST_LEAF]); cDepth = uni(lc[C_DEPTH]);
+    } else {
+        cN = uni(T->ctr[C_NODES]); cI = uni(T->ctr[C_IDS]); c8 = uni(T->ctr[C_N8]); c16 = uni(T->ctr[C_N16]);
+        c32 = uni(T->ctr[C_N32]); cRoot = SUB ? uni(gate_nodes[blockIdx.x]) : uni(T->ctr[C_ROOT]); cFirst = uni(T->ctr[C_FIRST_LEAF]);
+        cDepth = uni(T->ctr[C_DEPTH]);
+        if (tid < 8) stats[tid] = SUB ? 0ull : T->stats[tid];
+    }
     for (int ch = tid; ch < k.RBc; ch += TB) sx[ch] = (u32x4_t)(0);  // padding bytes stay zero
     __syncthreads();
     // LDS mirrors of the nodes on the most recent root-to-leaf path, one per level: consecutive
@@ -1370,11 +1379,12 @@ __device__ __forceinline__ void tree_insert_body(unsigned char* smem_raw, TreeDe
     const bool pf_ok = !bufmode && n_elems > 0 && ((((uintptr_t)in_rows) | (uintptr_t)row_stride) & 15) == 0 &&
                        (nb & 15) == 0 && k.RBc <= TB;
     u32x4_t pf = (u32x4_t)(0);
-    if (pf_ok && tid < k.RBc) pf = ldg<u32x4_t>(in_rows + (SUB ? (size_t)uni(gate_elems[g_off]) * (size_t)row_stride : 0) + (size_t)tid * 16);
+    long long e = ONE ? e_first : 0;
+    const long long e_end = ONE ? e_first + 1 : n_elems;
+    if (pf_ok && tid < k.RBc) pf = ldg<u32x4_t>(in_rows + (SUB ? (size_t)uni(gate_elems[g_off]) * (size_t)row_stride : (size_t)e * (size_t)row_stride) + (size_t)tid * 16);
 
-    long long e = 0;
     int stop = STOP_DONE;
-    for (; e < n_elems; ++e) {
+    for (; e < e_end; ++e) {
         // Elements meet here.  When the root is mirrored in LDS the first global read of the next
         // insertion (level 1) sits behind the full barrier that ends the root compare, so this
         // barrier only has to order LDS traffic: the previous insertion's HBM stores keep draining
@@ -1409,7 +1419,7 @@ __device__ __forceinline__ void tree_insert_body(unsigned char* smem_raw, TreeDe
                 // this row was requested while the previous element was being inserted
                 if (tid < k.RBc) sx[tid] = pf;
                 PHASE(15);
-                if (e + 1 < n_elems && tid < k.RBc) {
+                if (e + 1 < e_end && tid < k.RBc) {
                     const long long nidx = SUB ? (long long)uni(gate_elems[g_off + e + 1]) : e + 1;
                     pf = ldg<u32x4_t>(in_rows + nidx * row_stride + (size_t)tid * 16);
                 }
@@ -1836,6 +1846,15 @@ __device__ __forceinline__ void tree_insert_body(unsigned char* smem_raw, TreeDe
         if (tid < 7 && tid != 5 && tid != 6) atomicAdd((unsigned long long*)&T->stats[tid], (unsigned long long)stats[tid] );
         if (tid == 5) atomicAdd((unsigned long long*)&T->stats[5], (unsigned long long)stats[5]);
         if (tid == 0 && stop != STOP_DONE) atomicMax(&T->stop_reason, stop);
+    } else if constexpr (ONE) {
+        if (tid == 0) {
+            LA uint32_t* lc = lds<uint32_t>(k.L, k.o.ctr);
+            lc[C_NODES] = cN; lc[C_IDS] = cI; lc[C_N8] = c8; lc[C_N16] = c16; lc[C_N32] = c32;
+            lc[C_ROOT] = cRoot; lc[C_FIRST_LEAF] = cFirst; lc[C_DEPTH] = cDepth;
+            lc[8] = (uint32_t)stop;
+            lc[9] = (uint32_t)(e - e_first);
+        }
+        __syncthreads();
     } else {
         if (tid == 0) {
             T->ctr[C_NODES] = cN; T->ctr[C_IDS] = cI; T->ctr[C_N8] = c8; T->ctr[C_N16] = c16; T->ctr[C_N32] = c32;
@@ -1870,6 +1889,10 @@ __global__ __launch_bounds__(TB, 2) void k_tree_insert_dense(TreeDev* trees) {
     tree_insert_body<false, false, KCt>(smem_raw, trees, nullptr, nullptr, nullptr);
 }
 
+#endif  // __HIPCC__ (bb_tree_fast.inc has its own host / device split)
+#include "bb_tree_fast.inc"
+#if defined(__HIPCC__)
+
 // shapes with a specialised kernel (KCFix): the benchmark / test default and the CLI default
 using KC50 = KCFix<50, 2048>;
 using KC254 = KCFix<254, 2048>;
@@ -1884,6 +1907,12 @@ using KC50BT = KCWith<KC50, 1, BBH_CRIT_TOL_DIAMETER>;
 using KC50PT = KCWith<KC50, 0, BBH_CRIT_TOL_DIAMETER>;  // singleton runs of refine / merge rounds
 using KC254PD = KCWith<KC254, 0, BBH_CRIT_DIAMETER>;
 using KC254BT = KCWith<KC254, 1, BBH_CRIT_TOL_DIAMETER>;
+
+// the steady-state kernel (bb_tree_fast.inc) for the shapes that have one
+using KF50P = KF<50, 0, -1>;
+using KF50B = KF<50, 1, -1>;
+using KF254P = KF<254, 0, -1>;
+using KF254B = KF<254, 1, -1>;
 
 // uint8 BitFeature buffers with n_samples == 1 are plain fingerprints in unpacked form (ls in {0, 1}):
 // pack them (MSB first, np.packbits order) so that they take the fingerprint path of the kernel.
@@ -2231,6 +2260,18 @@ int configure(bbh_tree* t, int32_t bf, int32_t n_features) {
         BB_HIP(hipFuncSetAttribute((const void*)k_tree_insert<false, false, KC254P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->lds));
         BB_HIP(hipFuncSetAttribute((const void*)k_tree_insert<false, false, KC254B>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->lds));
     }
+    {
+        // the steady-state kernels use the CU's whole LDS whatever this tree's own layout needs
+        static bool fast_attr_done = false;
+        if (!fast_attr_done) {
+            BB_HIP(hipFuncSetAttribute((const void*)k_tree_fast<KF50P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast_layout(50).total));
+            BB_HIP(hipFuncSetAttribute((const void*)k_tree_fast<KF50B>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast_layout(50).total));
+            BB_HIP(hipFuncSetAttribute((const void*)k_tree_fast<KF50P, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast_layout(50).total));
+            BB_HIP(hipFuncSetAttribute((const void*)k_tree_fast<KF254P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast_layout(254).total));
+            BB_HIP(hipFuncSetAttribute((const void*)k_tree_fast<KF254B>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast_layout(254).total));
+            fast_attr_done = true;
+        }
+    }
     return BBH_OK;
 }
 
@@ -2311,7 +2352,26 @@ int run_insert_multi(std::vector<Job>& jobs, hipStream_t s) {
                 all50 = all50 && q.bf == 50 && q.F == 2048;
                 all254 = all254 && q.bf == 254 && q.F == 2048;
             }
-            if (prof_phases && all50)
+            // the steady-state kernel: 2048-bit rows, bf 50 / 254, criteria without extra reductions
+            static const bool no_fast = getenv("BBHIP_NO_FAST") != nullptr;
+            bool fast_ok = !no_fast && (all50 || all254);
+            bool f_packed = true, f_buffers = true;
+            for (size_t a = 0; a < active.size() && fast_ok; ++a) {
+                const Job& fj = jobs[active[a]];
+                const int c = fj.t->h.crit;
+                fast_ok = c == BBH_CRIT_DIAMETER || c == BBH_CRIT_TOL_DIAMETER || c == BBH_CRIT_TOL_LEGACY || c == BBH_CRIT_NEVER;
+                f_packed = f_packed && fj.bufs == nullptr;
+                f_buffers = f_buffers && fj.bufs != nullptr;
+            }
+            fast_ok = fast_ok && (f_packed || f_buffers);
+            if (fast_ok) {
+                const dim3 grid((unsigned)active.size()), block(TB);
+                if (all50 && f_packed && prof_phases) hipLaunchKernelGGL((k_tree_fast<KF50P, true>), grid, block, fast_layout(50).total, s, dptr);
+                else if (all50 && f_packed) hipLaunchKernelGGL((k_tree_fast<KF50P>), grid, block, fast_layout(50).total, s, dptr);
+                else if (all50) hipLaunchKernelGGL((k_tree_fast<KF50B>), grid, block, fast_layout(50).total, s, dptr);
+                else if (f_packed) hipLaunchKernelGGL((k_tree_fast<KF254P>), grid, block, fast_layout(254).total, s, dptr);
+                else hipLaunchKernelGGL((k_tree_fast<KF254B>), grid, block, fast_layout(254).total, s, dptr);
+            } else if (prof_phases && all50)
                 hipLaunchKernelGGL((k_tree_insert<true, false, KC50>), dim3((unsigned)active.size()), dim3(TB), lds, s, dptr,
                                    (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
             else if (prof_phases)

@@ -214,7 +214,7 @@ def run_multiround_bitbirch(
     if final_merge_criterion is None:
         final_merge_criterion = midsection_merge_criterion
     out_dir = Path(out_dir)
-    input_files = [Path(f) for f in input_files]
+    input_files = [Path(f) if isinstance(f, (Path, str)) else f for f in input_files]  # arrays / tensors: shards in memory
     common = dict(branching_factor=branching_factor, tolerance=tolerance, engine_factory=_engine_factory, device=device)
     timer = _Timer()
     timer.init_timing("total")

@@ -1,0 +1,114 @@
+r"""BASELINE configs 4 and 5 on the GPU: 8 shards through multiround - S-ecfp at threshold 0.3 with the CLI
+defaults, S-rdkit-like at threshold 0.6 with `initial_merge_criterion="diameter"` (reference multiround.py:333-484,
+_config.py:23-33).  50 k rows per shard against the oracle engine through the same host code (file-based and one
+rank per GPU); size-independent properties at 1 M rows per shard."""
+from __future__ import annotations
+
+import pickle
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+
+from oracle_engine import OracleEngine  # noqa: E402
+
+from bblean_amd.multiround import run_multiround_bitbirch, run_multiround_distributed  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+CONFIGS = {
+    "config4_ecfp": dict(workload="ecfp", kwargs=dict(threshold=0.3)),
+    "config5_rdkit": dict(workload="rdkit", kwargs=dict(threshold=0.6, initial_merge_criterion="diameter")),
+}
+
+
+def _shards(workload: str, n_shards: int, rows: int, seed0: int):
+    import torch
+
+    from bench import WORKLOADS
+
+    gen = WORKLOADS[workload][0]
+    return [gen(rows, seed0 + i, torch.device("cuda")) for i in range(n_shards)]
+
+
+def _single_rank_group():
+    import torch.distributed as dist
+
+    from test_scale_golden import _free_port
+
+    if not dist.is_initialized():
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1)
+    return dist
+
+
+@pytest.mark.parametrize("name", list(CONFIGS))
+def test_configs_4_5_8x50k_vs_oracle(name, tmp_path):
+    cfg = CONFIGS[name]
+    shards = _shards(cfg["workload"], 8, 50_000, 100)
+    files = []
+    for i, s in enumerate(shards):
+        f = tmp_path / f"fps.{i:04d}.npy"
+        np.save(f, s.cpu().numpy())
+        files.append(f)
+    outs = {}
+    for tag, fac in (("hip", None), ("oracle", OracleEngine)):
+        out = tmp_path / tag
+        out.mkdir()
+        run_multiround_bitbirch(files, out, num_initial_processes=1, _engine_factory=fac, **cfg["kwargs"])
+        outs[tag] = (pickle.load(open(out / "clusters.pkl", "rb")), pickle.load(open(out / "cluster-centroids-packed.pkl", "rb")))
+    assert outs["hip"][0] == outs["oracle"][0]
+    assert (np.array(outs["hip"][1]) == np.array(outs["oracle"][1])).all()
+    # one rank per GPU, shards resident in HBM, tables exchanged as device tensors
+    dist = _single_rank_group()
+    try:
+        clusters, timer = run_multiround_distributed(shards, None, **cfg["kwargs"])
+    finally:
+        dist.destroy_process_group()
+    assert clusters == outs["oracle"][0]
+    assert set(timer.timings) == {"round-1", "round-2", "round-3", "total"}
+
+
+@pytest.mark.parametrize("name", list(CONFIGS))
+def test_configs_4_5_properties_8x1M(name):
+    r"""Size-independent properties at 1 M rows per shard (8 M rows): the clusters partition the input, the final
+    cluster features add up to the column sums of ALL fingerprints (linearity across fit, refinement, both
+    exchanges and both merge rounds), sizes and labels agree."""
+    import torch
+
+    cfg = CONFIGS[name]
+    rows = 1_000_000
+    shards = _shards(cfg["workload"], 8, rows, 200)
+    n = 8 * rows
+    want = torch.zeros(2048, dtype=torch.int64, device="cuda")
+    shifts = torch.arange(7, -1, -1, device="cuda", dtype=torch.uint8)
+    for s in shards:
+        for lo in range(0, rows, 250_000):
+            bits = (s[lo:lo + 250_000, :, None] >> shifts) & 1
+            want += bits.view(-1, 2048).sum(dim=0, dtype=torch.int64)
+    dist = _single_rank_group()
+    try:
+        tree, timer = run_multiround_distributed(shards, None, return_tree=True, **cfg["kwargs"])
+    finally:
+        dist.destroy_process_group()
+    ids = tree.get_assignments()
+    assert ids.shape == (n,) and ids.min() == 1
+    lv = tree._leaves()
+    k = lv["ids"].size
+    assert int(ids.max()) == k
+    sizes = np.bincount(ids.astype(np.int64), minlength=k + 1)[1:]
+    order = tree._leaf_order(True)
+    assert (sizes == lv["n"][order].astype(np.int64)).all() and (np.diff(sizes) <= 0).all()
+    assert np.array_equal(np.sort(lv["members"]), np.arange(n))
+    bufs, mols = tree._bf_tables(order)
+    total = np.zeros(2048, dtype=np.uint64)
+    total_n = 0
+    for name_, table in bufs.items():
+        table = np.asarray(table)
+        total += table[:, :-1].sum(axis=0, dtype=np.uint64)
+        total_n += int(table[:, -1].sum(dtype=np.uint64))
+        assert (table[:, -1].astype(np.int64) == mols[name_].counts).all()
+    assert total_n == n
+    assert np.array_equal(total, want.cpu().numpy().astype(np.uint64))
