@@ -2362,6 +2362,8 @@ int run_insert_multi(std::vector<Job>& jobs, hipStream_t s) {
                 fast_ok = c == BBH_CRIT_DIAMETER || c == BBH_CRIT_TOL_DIAMETER || c == BBH_CRIT_TOL_LEGACY || c == BBH_CRIT_NEVER;
                 f_packed = f_packed && fj.bufs == nullptr;
                 f_buffers = f_buffers && fj.bufs != nullptr;
+                // packed rows are read with 16-byte loads straight into registers
+                if (fj.bufs == nullptr && ((((uintptr_t)fj.rows) | (uintptr_t)fj.row_stride) & 15) != 0) fast_ok = false;
             }
             fast_ok = fast_ok && (f_packed || f_buffers);
             if (fast_ok) {
@@ -2919,7 +2921,7 @@ extern "C" int bbh_tree_stats(bbh_tree* t, uint64_t* out8) {
         fprintf(stderr, "[bbhip phases, cycles/insert]");
         const double n = (double)(t->h.stats[2] + t->h.stats[3]);
         for (int i = 0; i < 8; ++i) fprintf(stderr, " p%d=%.0f", i, n > 0 ? (double)t->h.phase[i] / n : 0.0);
-        static const char* cls[3] = {"zero-skip", "mirror-hit", "miss"};
+        static const char* cls[3] = {"fill/miss", "tag-only", "compare"};  // (k_tree_fast; k_tree_insert: miss, zero-skip, mirror-hit)
         fprintf(stderr, "\n[bbhip p0 detail] loop-top barrier+checks=%.0f wait-for-prefetched-row=%.0f", n > 0 ? (double)t->h.phase[14] / n : 0.0,
                 n > 0 ? (double)t->h.phase[15] / n : 0.0);
         for (int i = 0; i < 3; ++i)

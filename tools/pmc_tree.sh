@@ -19,7 +19,7 @@ n = int(sys.argv[1])
 agg = collections.defaultdict(float)
 for f in glob.glob("/tmp/pmc_tree/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
-        if "k_tree_insert" in row.get("Kernel_Name", ""):
+        if "k_tree" in row.get("Kernel_Name", ""):
             agg[row["Counter_Name"]] += float(row["Counter_Value"] or 0)
 for k in sorted(agg):
     print(f"{k:24s} total={agg[k]:.4g}  per_insert={agg[k]/n:.1f}")
