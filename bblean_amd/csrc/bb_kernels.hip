@@ -463,7 +463,7 @@ extern "C" int bbh_jt_best_match(const uint8_t* queries, int64_t nq, const uint8
     BB_TRY(ou.init(out_union, (size_t)nq * 4));
     BB_TRY(os.init(out_sims, (size_t)nq * (size_t)nc * 8));
     uint32_t* ccard = nullptr;
-    BB_HIP(hipMalloc(&ccard, (size_t)nc * 4));
+    BB_HIP(bb::dev_alloc(&ccard, (size_t)nc * 4));
     int rc = launch_arr_vec<false>((const uint8_t*)c.dev, nc, nbytes, nbytes, nullptr, nullptr, nullptr,
                                    nullptr, nullptr, ccard, s);
     if (rc == BBH_OK && nq > 0) {
@@ -487,7 +487,7 @@ extern "C" int bbh_jt_best_match(const uint8_t* queries, int64_t nq, const uint8
     if (rc == BBH_OK) rc = ou.finish(s);
     if (rc == BBH_OK) rc = os.finish(s);
     hipError_t e = hipStreamSynchronize(s);
-    (void)hipFree(ccard);
+    bb::dev_free(ccard);
     if (rc == BBH_OK && e != hipSuccess) rc = bb::fail(BBH_ERR_HIP, "best_match: %s", hipGetErrorString(e));
     return rc;
 }
@@ -742,14 +742,14 @@ static int isim_dev(const void* ls_dev, int width, int64_t nf, int64_t n_objects
         return BBH_OK;
     }
     double* d = nullptr;
-    BB_HIP(hipMalloc(&d, 8));
+    BB_HIP(bb::dev_alloc(&d, 8));
     {
         bb::ProfScope ps("isim_from_sum", s);
         hipLaunchKernelGGL(k_isim_from_sum, dim3(1), dim3(256), 0, s, ls_dev, width, nf, (long long)n_objects, d);
     }
     hipError_t e = hipMemcpyAsync(out_host, d, 8, hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
-    (void)hipFree(d);
+    bb::dev_free(d);
     if (e != hipSuccess) return bb::fail(BBH_ERR_HIP, "isim_from_sum: %s", hipGetErrorString(e));
     return BBH_OK;
 }
@@ -776,11 +776,11 @@ extern "C" int bbh_isim_rows(const uint8_t* arr, int64_t n, int64_t n_cols, int 
     bb::DevIn a;
     BB_TRY(a.init(arr, (size_t)(n * n_cols), s));
     unsigned long long* ls = nullptr;
-    BB_HIP(hipMalloc(&ls, (size_t)n_features * 8));
+    BB_HIP(bb::dev_alloc(&ls, (size_t)n_features * 8));
     int rc = add_rows_dev((const uint8_t*)a.dev, n, n_cols, packed, n_features, ls, s);
     if (rc == BBH_OK) rc = isim_dev(ls, 8, n_features, n, out, warn, s);
     (void)hipStreamSynchronize(s);
-    (void)hipFree(ls);
+    bb::dev_free(ls);
     return rc;
 }
 
@@ -788,11 +788,36 @@ extern "C" int bbh_isim_rows(const uint8_t* arr, int64_t n, int64_t n_cols, int 
 // jt_most_dissimilar_packed (similarity.cpp:413-471) composed from the kernels above.
 // The tree engine has its own fused in-kernel version (bb_tree.hip, split_node).
 // =======================================================================================
-static int64_t host_first_argmin(const double* v, int64_t n) {
-    int64_t b = 0;
-    for (int64_t i = 1; i < n; ++i)
-        if (v[i] < v[b]) b = i;  // std::min_element: first minimum
-    return b;
+// first index of the minimum (std::min_element / np.argmin: the first one wins), one block; then the row it names
+// becomes the comparison vector of the next pass - both on the device, no host round trip in between
+__global__ __launch_bounds__(256) void k_first_argmin_row(const double* __restrict__ v, long long n, const uint8_t* __restrict__ Y,
+                                                          long long nbytes, long long* __restrict__ out_idx,
+                                                          uint8_t* __restrict__ out_row) {
+    __shared__ double sv[256];
+    __shared__ long long si[256];
+    __shared__ long long best;
+    const int t = threadIdx.x;
+    double bv = 0.0;
+    long long bi = -1;
+    for (long long i = t; i < n; i += 256) {
+        const double x = v[i];
+        if (bi < 0 || x < bv) { bv = x; bi = i; }  // ascending i per thread: strict < keeps the first
+    }
+    sv[t] = bv;
+    si[t] = bi;
+    __syncthreads();
+    for (int w = 128; w >= 1; w >>= 1) {
+        if (t < w) {
+            const long long oi = si[t + w];
+            const double ov = sv[t + w];
+            if (oi >= 0 && (si[t] < 0 || ov < sv[t] || (ov == sv[t] && oi < si[t]))) { sv[t] = ov; si[t] = oi; }
+        }
+        __syncthreads();
+    }
+    if (t == 0) { best = si[0]; *out_idx = si[0]; }
+    __syncthreads();
+    const long long b = best;
+    for (long long i = t; i < nbytes; i += 256) out_row[i] = Y[b * nbytes + i];
 }
 
 extern "C" int bbh_most_dissimilar(const uint8_t* Y, int64_t n, int64_t nbytes, int64_t n_features,
@@ -811,16 +836,21 @@ extern "C" int bbh_most_dissimilar(const uint8_t* Y, int64_t n, int64_t nbytes, 
     BB_TRY(o2.init(sims2, (size_t)n * 8));
     const uint8_t* yd = (const uint8_t*)y.dev;
     void* scratch = nullptr;
+    const size_t rowb = ((size_t)nbytes + 15) / 16 * 16;
     const size_t sz_ls = (size_t)nbytes * 8 * 8, sz_card = (size_t)n * 4, sz_sim = (size_t)n * 8;
-    const size_t off_cen = sz_ls, off_card = off_cen + ((nbytes + 15) / 16) * 16;
+    const size_t off_cen = sz_ls, off_r1 = off_cen + rowb, off_r2 = off_r1 + rowb, off_idx = off_r2 + rowb;
+    const size_t off_card = off_idx + 16;
     const size_t off_sim = (off_card + sz_card + 15) / 16 * 16;
-    BB_HIP(hipMalloc(&scratch, off_sim + 2 * sz_sim));
+    BB_HIP(bb::dev_alloc(&scratch, off_sim + 2 * sz_sim));
     auto* ls = (unsigned long long*)scratch;
     auto* cen = (uint8_t*)scratch + off_cen;
+    auto* row1 = (uint8_t*)scratch + off_r1;
+    auto* row2 = (uint8_t*)scratch + off_r2;
+    auto* didx = (long long*)((uint8_t*)scratch + off_idx);
     auto* card = (uint32_t*)((uint8_t*)scratch + off_card);
     auto* simc = (double*)((uint8_t*)scratch + off_sim);
     auto* sim_tmp = simc + n;
-    std::vector<double> h((size_t)n);
+    long long hidx[2] = {0, 0};
     int rc = BBH_OK;
     auto run = [&]() -> int {
         BB_HIP(hipMemsetAsync(cen, 0, (size_t)nbytes, s));
@@ -829,19 +859,16 @@ extern "C" int bbh_most_dissimilar(const uint8_t* Y, int64_t n, int64_t nbytes, 
                            (const void*)ls, 8, n_features, n, 1, cen);
         BB_TRY(launch_arr_vec<false>(yd, n, nbytes, nbytes, nullptr, nullptr, nullptr, nullptr, nullptr, card, s));
         BB_TRY(launch_arr_vec<true>(yd, n, nbytes, nbytes, cen, card, simc, nullptr, nullptr, nullptr, s));
-        BB_HIP(hipMemcpyAsync(h.data(), simc, sz_sim, hipMemcpyDeviceToHost, s));
-        BB_HIP(hipStreamSynchronize(s));
-        const int64_t f1 = host_first_argmin(h.data(), n);
+        hipLaunchKernelGGL(k_first_argmin_row, dim3(1), dim3(256), 0, s, (const double*)simc, (long long)n, yd, (long long)nbytes,
+                           didx, row1);
         double* d1 = o1.dev ? (double*)o1.dev : sim_tmp;
-        BB_TRY(launch_arr_vec<true>(yd, n, nbytes, nbytes, yd + f1 * nbytes, card, d1, nullptr, nullptr, nullptr, s));
-        BB_HIP(hipMemcpyAsync(h.data(), d1, sz_sim, hipMemcpyDeviceToHost, s));
-        BB_HIP(hipStreamSynchronize(s));
-        const int64_t f2 = host_first_argmin(h.data(), n);
+        BB_TRY(launch_arr_vec<true>(yd, n, nbytes, nbytes, row1, card, d1, nullptr, nullptr, nullptr, s));
+        hipLaunchKernelGGL(k_first_argmin_row, dim3(1), dim3(256), 0, s, (const double*)d1, (long long)n, yd, (long long)nbytes,
+                           didx + 1, row2);
         if (o2.dev)
-            BB_TRY(launch_arr_vec<true>(yd, n, nbytes, nbytes, yd + f2 * nbytes, card, (double*)o2.dev, nullptr,
-                                        nullptr, nullptr, s));
-        *idx1 = f1;
-        *idx2 = f2;
+            BB_TRY(launch_arr_vec<true>(yd, n, nbytes, nbytes, row2, card, (double*)o2.dev, nullptr, nullptr, nullptr, s));
+        BB_HIP(hipGetLastError());
+        BB_HIP(hipMemcpyAsync(hidx, didx, 16, hipMemcpyDeviceToHost, s));
         return BBH_OK;
     };
     {
@@ -851,8 +878,12 @@ extern "C" int bbh_most_dissimilar(const uint8_t* Y, int64_t n, int64_t nbytes, 
     if (rc == BBH_OK) rc = o1.finish(s);
     if (rc == BBH_OK) rc = o2.finish(s);
     hipError_t e = hipStreamSynchronize(s);
-    (void)hipFree(scratch);
+    bb::dev_free(scratch);
     if (rc == BBH_OK && e != hipSuccess) rc = bb::fail(BBH_ERR_HIP, "most_dissimilar: %s", hipGetErrorString(e));
+    if (rc == BBH_OK) {
+        *idx1 = hidx[0];
+        *idx2 = hidx[1];
+    }
     return rc;
 }
 

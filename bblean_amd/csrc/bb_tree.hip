@@ -1893,26 +1893,29 @@ __global__ __launch_bounds__(TB, 2) void k_tree_insert_dense(TreeDev* trees) {
 #include "bb_tree_fast.inc"
 #if defined(__HIPCC__)
 
-// shapes with a specialised kernel (KCFix): the benchmark / test default and the CLI default
+// the complete engine compiled for the benchmark shape with phase timers (tools/phases.py with BBHIP_NO_FAST=1)
 using KC50 = KCFix<50, 2048>;
-using KC254 = KCFix<254, 2048>;
-using KC50P = KCWith<KC50, 0>;  // ... inserting packed fingerprints
-using KC50B = KCWith<KC50, 1>;  // ... inserting BitFeature buffers
-using KC254P = KCWith<KC254, 0>;
-using KC254B = KCWith<KC254, 1>;
-// ... with the criteria of the standard pipelines: diameter for fingerprints (`fit`), tolerance-diameter
-// for BitFeature buffers (refine, merge rounds)
-using KC50PD = KCWith<KC50, 0, BBH_CRIT_DIAMETER>;
-using KC50BT = KCWith<KC50, 1, BBH_CRIT_TOL_DIAMETER>;
-using KC50PT = KCWith<KC50, 0, BBH_CRIT_TOL_DIAMETER>;  // singleton runs of refine / merge rounds
-using KC254PD = KCWith<KC254, 0, BBH_CRIT_DIAMETER>;
-using KC254BT = KCWith<KC254, 1, BBH_CRIT_TOL_DIAMETER>;
 
 // the steady-state kernel (bb_tree_fast.inc) for the shapes that have one
 using KF50P = KF<50, 0, -1>;
 using KF50B = KF<50, 1, -1>;
 using KF254P = KF<254, 0, -1>;
 using KF254B = KF<254, 1, -1>;
+
+// Kernel instances by (branching factor, element kind): one table instead of a ladder of launch statements.  Shapes
+// without an entry run the complete engine with the shape as run-time values (k_tree_insert<.., KC>).
+struct FastKernel {
+    int bf;
+    bool buffers;
+    void (*fn)(TreeDev*);
+    uint32_t lds;
+};
+static const FastKernel kFastKernels[] = {
+    {50, false, k_tree_fast<KF50P>, fast_layout(50).total},
+    {50, true, k_tree_fast<KF50B>, fast_layout(50).total},
+    {254, false, k_tree_fast<KF254P>, fast_layout(254).total},
+    {254, true, k_tree_fast<KF254B>, fast_layout(254).total},
+};
 
 // uint8 BitFeature buffers with n_samples == 1 are plain fingerprints in unpacked form (ls in {0, 1}):
 // pack them (MSB first, np.packbits order) so that they take the fingerprint path of the kernel.
@@ -2239,36 +2242,27 @@ int configure(bbh_tree* t, int32_t bf, int32_t n_features) {
     if (h.scratch_cent) bb::dev_free(h.scratch_cent);
     h.scratch_cent = nullptr;
     BB_HIP(bb::dev_alloc(&h.scratch_cent, ((size_t)bf + 1) * h.RB));
-    if (t->lds > 48 * 1024)
     {
-        BB_HIP(hipFuncSetAttribute((const void*)k_tree_insert<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->lds));
-        BB_HIP(hipFuncSetAttribute((const void*)k_tree_insert<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->lds));
-        BB_HIP(hipFuncSetAttribute((const void*)k_tree_insert<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->lds));
-        BB_HIP(hipFuncSetAttribute((const void*)k_tree_insert_dense<KC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->lds));
-        BB_HIP(hipFuncSetAttribute((const void*)k_tree_insert<false, false, KC50P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->lds));
-        BB_HIP(hipFuncSetAttribute((const void*)k_tree_insert<false, false, KC50B>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->lds));
-        BB_HIP(hipFuncSetAttribute((const void*)k_tree_insert_dense<KC50P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->lds));
-        BB_HIP(hipFuncSetAttribute((const void*)k_tree_insert_dense<KC50B>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->lds));
-        BB_HIP(hipFuncSetAttribute((const void*)k_tree_insert<false, false, KC50PD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->lds));
-        BB_HIP(hipFuncSetAttribute((const void*)k_tree_insert<false, false, KC50BT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->lds));
-        BB_HIP(hipFuncSetAttribute((const void*)k_tree_insert<false, false, KC50PT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->lds));
-        BB_HIP(hipFuncSetAttribute((const void*)k_tree_insert_dense<KC50PD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->lds));
-        BB_HIP(hipFuncSetAttribute((const void*)k_tree_insert_dense<KC50BT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->lds));
-        BB_HIP(hipFuncSetAttribute((const void*)k_tree_insert<false, false, KC254PD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->lds));
-        BB_HIP(hipFuncSetAttribute((const void*)k_tree_insert<false, false, KC254BT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->lds));
-        BB_HIP(hipFuncSetAttribute((const void*)k_tree_insert<true, false, KC50>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->lds));
-        BB_HIP(hipFuncSetAttribute((const void*)k_tree_insert<false, false, KC254P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->lds));
-        BB_HIP(hipFuncSetAttribute((const void*)k_tree_insert<false, false, KC254B>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->lds));
+        // dynamic LDS above 48 KiB has to be allowed per kernel; the attribute is process-wide, so it is only ever
+        // raised: to the CU's 160 KiB, once (trees of different shapes share the kernels)
+        static bool attr_done = false;
+        if (!attr_done) {
+            const int cap = 160 * 1024;
+            BB_HIP(hipFuncSetAttribute((const void*)k_tree_insert<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+            BB_HIP(hipFuncSetAttribute((const void*)k_tree_insert<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+            BB_HIP(hipFuncSetAttribute((const void*)k_tree_insert<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+            BB_HIP(hipFuncSetAttribute((const void*)k_tree_insert_dense<KC>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+            BB_HIP(hipFuncSetAttribute((const void*)k_tree_insert<true, false, KC50>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+            attr_done = true;
+        }
     }
     {
         // the steady-state kernels use the CU's whole LDS whatever this tree's own layout needs
         static bool fast_attr_done = false;
         if (!fast_attr_done) {
-            BB_HIP(hipFuncSetAttribute((const void*)k_tree_fast<KF50P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast_layout(50).total));
-            BB_HIP(hipFuncSetAttribute((const void*)k_tree_fast<KF50B>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast_layout(50).total));
+            for (const FastKernel& fk : kFastKernels)
+                BB_HIP(hipFuncSetAttribute((const void*)fk.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fk.lds));
             BB_HIP(hipFuncSetAttribute((const void*)k_tree_fast<KF50P, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast_layout(50).total));
-            BB_HIP(hipFuncSetAttribute((const void*)k_tree_fast<KF254P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast_layout(254).total));
-            BB_HIP(hipFuncSetAttribute((const void*)k_tree_fast<KF254B>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast_layout(254).total));
             fast_attr_done = true;
         }
     }
@@ -2366,52 +2360,24 @@ int run_insert_multi(std::vector<Job>& jobs, hipStream_t s) {
                 if (fj.bufs == nullptr && ((((uintptr_t)fj.rows) | (uintptr_t)fj.row_stride) & 15) != 0) fast_ok = false;
             }
             fast_ok = fast_ok && (f_packed || f_buffers);
-            if (fast_ok) {
-                const dim3 grid((unsigned)active.size()), block(TB);
-                if (all50 && f_packed && prof_phases) hipLaunchKernelGGL((k_tree_fast<KF50P, true>), grid, block, fast_layout(50).total, s, dptr);
-                else if (all50 && f_packed) hipLaunchKernelGGL((k_tree_fast<KF50P>), grid, block, fast_layout(50).total, s, dptr);
-                else if (all50) hipLaunchKernelGGL((k_tree_fast<KF50B>), grid, block, fast_layout(50).total, s, dptr);
-                else if (f_packed) hipLaunchKernelGGL((k_tree_fast<KF254P>), grid, block, fast_layout(254).total, s, dptr);
-                else hipLaunchKernelGGL((k_tree_fast<KF254B>), grid, block, fast_layout(254).total, s, dptr);
-            } else if (prof_phases && all50)
-                hipLaunchKernelGGL((k_tree_insert<true, false, KC50>), dim3((unsigned)active.size()), dim3(TB), lds, s, dptr,
-                                   (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
-            else if (prof_phases)
-                hipLaunchKernelGGL((k_tree_insert<true, false>), dim3((unsigned)active.size()), dim3(TB), lds, s, dptr,
-                                   (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
-            else {
-                const bool dense = dense_launch(active.size(), lds);
-                const dim3 grid((unsigned)active.size()), block(TB);
+            const FastKernel* fk = nullptr;
+            if (fast_ok)
+                for (const FastKernel& c : kFastKernels)
+                    if (c.bf == (all50 ? 50 : 254) && c.buffers == f_buffers) fk = &c;
+            const dim3 grid((unsigned)active.size()), block(TB);
+            if (fk != nullptr && prof_phases && all50 && f_packed) {
+                hipLaunchKernelGGL((k_tree_fast<KF50P, true>), grid, block, fk->lds, s, dptr);
+            } else if (fk != nullptr) {
+                hipLaunchKernelGGL(fk->fn, grid, block, fk->lds, s, dptr);
+            } else if (prof_phases) {
                 const uint32_t* const nu = nullptr;
-                // every job of a launch is of one kind (the entry points are per kind)
-                bool packed = true, buffers = true;
-                for (size_t a = 0; a < active.size(); ++a) {
-                    packed = packed && jobs[active[a]].bufs == nullptr;
-                    buffers = buffers && jobs[active[a]].bufs != nullptr;
-                }
-                if (!packed && !buffers) all50 = all254 = false;
-                bool diam = true, told = true;  // every tree on the standard criterion of its element kind?
-                for (size_t a = 0; a < active.size(); ++a) {
-                    diam = diam && jobs[active[a]].t->h.crit == BBH_CRIT_DIAMETER;
-                    told = told && jobs[active[a]].t->h.crit == BBH_CRIT_TOL_DIAMETER;
-                }
-                if (dense && all50 && packed && diam) hipLaunchKernelGGL(k_tree_insert_dense<KC50PD>, grid, block, lds, s, dptr);
-                else if (dense && all50 && buffers && told) hipLaunchKernelGGL(k_tree_insert_dense<KC50BT>, grid, block, lds, s, dptr);
-                else if (!dense && all50 && packed && diam) hipLaunchKernelGGL((k_tree_insert<false, false, KC50PD>), grid, block, lds, s, dptr, nu, nu, nu);
-                else if (!dense && all50 && buffers && told) hipLaunchKernelGGL((k_tree_insert<false, false, KC50BT>), grid, block, lds, s, dptr, nu, nu, nu);
-                else if (!dense && all50 && packed && told) hipLaunchKernelGGL((k_tree_insert<false, false, KC50PT>), grid, block, lds, s, dptr, nu, nu, nu);
-                else if (!dense && all254 && packed && diam) hipLaunchKernelGGL((k_tree_insert<false, false, KC254PD>), grid, block, lds, s, dptr, nu, nu, nu);
-                else if (!dense && all254 && buffers && told) hipLaunchKernelGGL((k_tree_insert<false, false, KC254BT>), grid, block, lds, s, dptr, nu, nu, nu);
-                else if (dense && all50 && packed) hipLaunchKernelGGL(k_tree_insert_dense<KC50P>, grid, block, lds, s, dptr);
-                else if (dense && all50) hipLaunchKernelGGL(k_tree_insert_dense<KC50B>, grid, block, lds, s, dptr);
-                else if (dense) hipLaunchKernelGGL(k_tree_insert_dense<KC>, grid, block, lds, s, dptr);
-                else if (all50 && packed) hipLaunchKernelGGL((k_tree_insert<false, false, KC50P>), grid, block, lds, s, dptr, nu, nu, nu);
-                else if (all50) hipLaunchKernelGGL((k_tree_insert<false, false, KC50B>), grid, block, lds, s, dptr, nu, nu, nu);
-                else if (all254 && packed) hipLaunchKernelGGL((k_tree_insert<false, false, KC254P>), grid, block, lds, s, dptr, nu, nu, nu);
-                else if (all254) hipLaunchKernelGGL((k_tree_insert<false, false, KC254B>), grid, block, lds, s, dptr, nu, nu, nu);
-                else
-                    hipLaunchKernelGGL((k_tree_insert<false, false, KC>), grid, block, lds, s, dptr, (const uint32_t*)nullptr,
-                                       (const uint32_t*)nullptr, (const uint32_t*)nullptr);
+                if (all50) hipLaunchKernelGGL((k_tree_insert<true, false, KC50>), grid, block, lds, s, dptr, nu, nu, nu);
+                else hipLaunchKernelGGL((k_tree_insert<true, false>), grid, block, lds, s, dptr, nu, nu, nu);
+            } else {
+                // the complete engine, shape as run-time values; two workgroups per CU when there are more trees than CUs
+                const uint32_t* const nu = nullptr;
+                if (dense_launch(active.size(), lds)) hipLaunchKernelGGL(k_tree_insert_dense<KC>, grid, block, lds, s, dptr);
+                else hipLaunchKernelGGL((k_tree_insert<false, false, KC>), grid, block, lds, s, dptr, nu, nu, nu);
             }
             e = hipGetLastError();
         }

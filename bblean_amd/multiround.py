@@ -20,6 +20,7 @@ Two front ends over the same round logic:
 """
 from __future__ import annotations
 
+import itertools
 import math
 import pickle
 import time
@@ -173,7 +174,9 @@ def _load_pair(buf_path: Path, idx_path: Path) -> tuple[NDArray[np.integer], _In
     with open(idx_path, "rb") as f:
         lists = pickle.load(f)
     bufs = np.load(buf_path, mmap_mode="r")
-    return bufs, _IndexLists.from_sequences(lists, len(lists))
+    counts = np.fromiter(map(len, lists), dtype=np.int64, count=len(lists))
+    flat = np.fromiter(itertools.chain.from_iterable(lists), dtype=np.int64, count=int(counts.sum()))
+    return bufs, _IndexLists(counts, flat)
 
 
 def run_multiround_bitbirch(
@@ -203,6 +206,7 @@ def run_multiround_bitbirch(
     cleanup: bool = True,
     device: int = 0,
     _engine_factory: tp.Any = None,
+    _round1_engine_factory: tp.Any = "same",
 ) -> _Timer:
     r"""File-compatible multiround on one GPU.  The process-count arguments are accepted for
     signature compatibility; the result never depended on them (tests/test_multiround.py of the
@@ -222,11 +226,13 @@ def run_multiround_bitbirch(
     round_idx = 1
     timer.init_timing(f"round-{round_idx}")
     infos = _files_range_tuples(input_files)
+    # (test hook: round 1 on another engine than the merge rounds - the round-* files are the wire format between them)
+    r1 = common if _round1_engine_factory == "same" else dict(common, engine_factory=_round1_engine_factory)
     for info, (bufs, mols) in zip(infos, _initial_rounds(
             infos, threshold=threshold, merge_criterion=initial_merge_criterion,
             refinement=refinement_before_midsection, refine_merge_criterion=midsection_merge_criterion,
             refine_threshold_change=midsection_threshold_change, n_features=n_features,
-            input_is_packed=input_is_packed, max_fps=max_fps, **common)):
+            input_is_packed=input_is_packed, max_fps=max_fps, **r1)):
         _save_tables(out_dir, bufs, mols, info[0], 1)
     timer.end_timing(f"round-{round_idx}")
 

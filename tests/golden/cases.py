@@ -195,3 +195,54 @@ def clustered_hier(n: int, n_features: int, n_super: int, k: int, seed: int,
     which = rng.integers(0, k, n)
     bits = protos[which] ^ (rng.random((n, n_features)) < flip_member)
     return np.packbits(bits.astype(np.uint8), axis=1)
+
+
+# ---- `bb run` as a call sequence (reference cli.py:1058-1121), shared by make_golden_scale.py and the parity tests ----
+def bb_run_sequence(BitBirch_, files, *, branching_factor, threshold, merge_criterion, tolerance, refine_merge_criterion,
+                    refine_threshold_change, refine_rounds, refine_num, recluster_rounds, before_release=None, **tree_kw):
+    r"""The calls `bb run` makes, in its order (reference cli.py:1058-1121, "lean" variant): the parity tests replay
+    exactly this function with bblean_amd.bitbirch.BitBirch."""
+    tree = BitBirch_(branching_factor=branching_factor, threshold=threshold, merge_criterion=merge_criterion,
+                     tolerance=tolerance, **tree_kw)
+    for file in files:
+        tree.fit(file, n_features=None, input_is_packed=True, max_fps=None)
+    if recluster_rounds != 0 or refine_rounds != 0:
+        tree.set_merge(refine_merge_criterion, tolerance=tolerance, threshold=threshold + refine_threshold_change)
+        for _ in range(refine_rounds):
+            tree.refine_inplace(files, input_is_packed=True, n_largest=refine_num)
+        for _ in range(recluster_rounds):
+            tree.recluster_inplace(shuffle=False)
+    extra = before_release(tree) if before_release is not None else None
+    tree.delete_internal_nodes()
+    return tree.get_centroids_mol_ids(), extra
+
+
+BBRUN_CASES = {
+    # `bb run dir -b 50 -t 0.65` of the reference's tests/test_cli.py:266-308 (CLI defaults otherwise)
+    "cli_golden": dict(files=[(3000, 12620509540149709235)], branching_factor=50, threshold=0.65, merge_criterion="diameter",
+                       tolerance=0.05, refine_merge_criterion="tolerance-diameter", refine_threshold_change=0.0,
+                       refine_rounds=0, refine_num=1, recluster_rounds=0),
+    # two input files, one refinement round splitting the 2 largest clusters (re-read from the FILE LIST: ascending
+    # global index, SURVEY.md section 8a rule 12), one recluster round
+    "two_files_refine": dict(files=[(1800, 2001), (1700, 2002)], branching_factor=50, threshold=0.3, merge_criterion="diameter",
+                             tolerance=0.05, refine_merge_criterion="tolerance-diameter", refine_threshold_change=0.0,
+                             refine_rounds=1, refine_num=2, recluster_rounds=1),
+}
+
+
+def _sha(a) -> str:
+    import hashlib
+
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def leaf_bfs_digest(tree) -> dict:
+    bfs = tree._get_leaf_bfs()
+    ns = np.array([bf.n_samples for bf in bfs], dtype="<i8")
+    cents = np.array([np.asarray(bf.packed_centroid) for bf in bfs], dtype=np.uint8)
+    mols = np.array([i for bf in bfs for i in bf.mol_indices], dtype="<i8")
+    ls = np.array([np.asarray(bf.linear_sum, dtype="<u8") for bf in bfs[:16]])
+    names = [bf.dtype_name for bf in bfs[:16]]
+    return {"k": len(bfs), "n_sha": _sha(ns), "cent_sha": _sha(cents), "mol_sha": _sha(mols), "ls16_sha": _sha(ls), "dtype16": names}
+
+

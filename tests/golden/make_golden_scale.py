@@ -34,7 +34,8 @@ from bblean import BitBirch  # noqa: E402
 from bblean.fingerprints import make_fake_fingerprints  # noqa: E402
 from bblean.multiround import run_multiround_bitbirch  # noqa: E402
 
-from cases import MULTIROUND_CASES, MULTIROUND_SCALE_CASES, SCALE_CASES, make_input, multiround_shard  # noqa: E402
+from cases import (BBRUN_CASES, MULTIROUND_CASES, MULTIROUND_SCALE_CASES, SCALE_CASES, bb_run_sequence,  # noqa: E402
+                   leaf_bfs_digest, make_input, multiround_shard)
 
 OUT = HERE / "scale.json"
 
@@ -105,6 +106,41 @@ def main() -> None:
             "files": files, "clusters": len(clusters), "sizes_sha": sha(sizes), "members_sha": sha(flat),
             "cent_sha": sha(np.array(cents, dtype=np.uint8)), "ref_seconds": round(dt, 2)}
         print(case["name"], f"{dt:.1f}s", len(clusters), "clusters", len(files), "round files", flush=True)
+        OUT.write_text(json.dumps(rec, indent=1, sort_keys=True))
+    bbrun_goldens(rec, want)
+
+
+def bbrun_goldens(rec: dict, want: set) -> None:
+    from bblean.similarity import jt_stratified_sampling
+
+    for name, case in BBRUN_CASES.items():
+        if want and name not in want:
+            continue
+        with tempfile.TemporaryDirectory() as d:
+            files = []
+            arrays = []
+            for i, (n, seed) in enumerate(case["files"]):
+                f = Path(d) / f"fingerprints.{i}.npy"
+                arr = make_fake_fingerprints(n, n_features=2048, seed=seed, pack=True)
+                np.save(f, arr)
+                files.append(f)
+                arrays.append(arr)
+            kw = {k: v for k, v in case.items() if k != "files"}
+            out, leaf = bb_run_sequence(BitBirch, files, before_release=leaf_bfs_digest, **kw)
+            fps = np.concatenate(arrays)
+            # analysis helpers on the same tree / input (reference bitbirch.py:909-967, similarity.py:276-304)
+            tree2 = BitBirch(branching_factor=case["branching_factor"], threshold=case["threshold"]).fit(fps)
+            med = tree2.get_medoids(fps)
+            samp = jt_stratified_sampling(fps[:500], 25)
+        sizes = np.array([len(c) for c in out["mol_ids"]], dtype="<i8")
+        flat = np.array([i for c in out["mol_ids"] for i in c], dtype="<i8")
+        rec.setdefault("bbrun", {})[name] = {
+            "clusters": len(out["mol_ids"]), "sizes_sha": sha(sizes), "members_sha": sha(flat),
+            "cent_sha": sha(np.array(out["centroids"], dtype=np.uint8)), "first13": [list(map(int, c)) for c in out["mol_ids"][:13]],
+            "leaf_bfs": leaf, "medoids_sha": sha(np.asarray(med, dtype=np.uint8)),
+            "sampling": [int(i) for i in np.asarray(samp).tolist()],
+        }
+        print("bbrun", name, len(out["mol_ids"]), "clusters", flush=True)
         OUT.write_text(json.dumps(rec, indent=1, sort_keys=True))
 
 

@@ -160,3 +160,18 @@ def test_sim_matrix_matches_rowwise():
         row = S.jt_sim_packed(fps, fps[i])
         row[i] = 1.0
         assert (m[i] == row).all()
+
+
+@pytest.mark.parametrize("nf", [2048, 2024, 64, 13])
+def test_pack_matches_packbits(nf):
+    r"""`bbh_pack` = pack_fingerprints = np.packbits(axis=-1), MSB first, last byte zero-padded (fingerprints.py:46-49)."""
+    import ctypes as C
+
+    from bblean_amd import _lib
+
+    lib = _lib.load()
+    rng = np.random.default_rng(nf)
+    un = (rng.random((37, nf)) < 0.3).astype(np.uint8) * rng.integers(1, 255, (37, nf), dtype=np.uint8)  # any non-zero is a set bit
+    out = np.empty((37, (nf + 7) // 8), dtype=np.uint8)
+    _lib.check(lib.bbh_pack(un.ctypes.data, 37, nf, out.ctypes.data, None))
+    assert (out == np.packbits(un != 0, axis=-1)).all()

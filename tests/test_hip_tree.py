@@ -168,6 +168,24 @@ def test_hip_tree_full_size_1M_vs_oracle():
     assert (lv_h["cents"] == lv_o["cents"]).all() and (lv_h["n"] == lv_o["n"]).all()
 
 
+@pytest.mark.parametrize("bf", [254, 1000])
+def test_hip_tree_1M_large_branching_factors_vs_oracle(bf):
+    r"""The CLI default (bf 254) and the branching factor the reference recommends for 100-200 M molecules (bf 1000,
+    docs/src/user-guide/parameters.rst:95-98) at 1 M rows: cluster ids, centroids and counters equal the oracle's.
+    bf 1000 has no LDS-resident nodes (1001 x 272 B > 160 KiB): every level is compared straight from L2 / HBM."""
+    import torch
+
+    from bench import synth_fake_fps
+
+    fps = synth_fake_fps(1_000_000, seed=2000 + bf, device=torch.device("cuda"))
+    hip = BitBirch(branching_factor=bf, threshold=0.3, merge_criterion="diameter").fit(fps)
+    ora = BitBirch(branching_factor=bf, threshold=0.3, merge_criterion="diameter", _engine_factory=OracleEngine).fit(fps.cpu().numpy())
+    assert (hip.get_assignments() == ora.get_assignments()).all()
+    assert hip._engine.stats()[:7].tolist() == ora._engine.stats()[:7].tolist()
+    lv_h, lv_o = hip._leaves(), ora._leaves()
+    assert (lv_h["cents"] == lv_o["cents"]).all() and (lv_h["n"] == lv_o["n"]).all()
+
+
 @pytest.mark.parametrize("n,k,thr,bf,batch", [(60_000, 3000, 0.6, 50, 256), (40_000, 400, 0.7, 20, 128),
                                              (50_000, 5000, 0.5, 50, 512)])
 def test_hip_batch_mode_concurrent_gates_vs_oracle(n, k, thr, bf, batch, monkeypatch):

@@ -118,3 +118,27 @@ def test_configs_4_5_distributed_world2_hip_device_tables(case, tmp_path):
     rank - no NumPy table on the way."""
     ex = _run_distributed(case, tmp_path, use_oracle=False, backend="gloo", world=2)
     assert sum(b["sent"] for per in ex for b in per.values()) > 0
+
+
+# ---- the round-* files as a wire format between engines (SURVEY.md section 8f rank 1) -------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("first,rest", [("hip", "oracle"), ("oracle", "hip")])
+def test_round_files_interoperate_between_engines(first, rest, tmp_path):
+    r"""Round 1 on one engine, its round-1 files merged by the other: HIP shards feed CPU merge rounds and CPU shards
+    feed HIP merge rounds, byte-identical files and the reference's clusters either way."""
+    from cases import MULTIROUND_CASES
+    from scale_cases import SCALE, file_digest
+
+    from bblean_amd.multiround import run_multiround_bitbirch
+
+    case = next(c for c in MULTIROUND_CASES if c["name"] == "mr_defaults")
+    fac = {"hip": None, "oracle": OracleEngine}
+    files = write_shards(tmp_path, case)
+    (tmp_path / "out").mkdir()
+    run_multiround_bitbirch(files, tmp_path / "out", num_initial_processes=1, cleanup=False, _engine_factory=fac[rest],
+                            _round1_engine_factory=fac[first], **case["kwargs"])
+    gold = SCALE["multiround"][case["name"]]
+    for p in sorted((tmp_path / "out").glob("round-*")):
+        assert file_digest(p) == gold["files"][p.name], p.name
+    check_final(case, pickle.load(open(tmp_path / "out" / "clusters.pkl", "rb")),
+                pickle.load(open(tmp_path / "out" / "cluster-centroids-packed.pkl", "rb")))

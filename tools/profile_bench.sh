@@ -3,15 +3,16 @@
 # PMC passes (FETCH_SIZE / WRITE_SIZE) as MI355X_MICROARCH.md prescribes.  Summaries land
 # under gpurun_out/prof_<tag>/ ; copy what should be judged into profiles/.
 set -uo pipefail
-TAG="${1:-r01}"
+TAG="${1:-r02}"
 NFPS="${2:-200000}"
+K1ROWS="${3:-8000000}"   # the arr-vec kernel is profiled on an array larger than the 256 MiB Infinity Cache
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 FINAL="$ROOT/gpurun_out/prof_$TAG"
 OUT="/tmp/prof_$TAG"
 rm -rf "$OUT"; mkdir -p "$OUT" "$FINAL"
 export TMPDIR=/tmp
 cd /tmp
-CMD="python $ROOT/bench.py --steps 1 --warmup 0 --n-fps $NFPS --no-cpu --shards 0 --multiround-files 0 --k1-rows $NFPS"
+CMD="python $ROOT/bench.py --steps 1 --warmup 0 --n-fps $NFPS --no-cpu --shards 0 --multiround-files 0 --k1-rows $K1ROWS"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o bench -- $CMD > "$OUT/bench_trace.log" 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o bench -- $CMD > "$OUT/bench_pmc_fetch.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o bench -- $CMD > "$OUT/bench_pmc_write.log" 2>&1
@@ -36,7 +37,7 @@ for name in ("pmc_fetch", "pmc_write"):
             for (k, c), (n, v) in sorted(agg.items()):
                 line = f"{k:60s} {c:12s} dispatches={n:6d} total={v:.1f} per_dispatch={v/max(n,1):.1f}"
                 print(line); w.write(line + "\n")
-                if "k_tree_insert" in k:
+                if "k_tree" in k:
                     rec["tree_" + ("fetch" if c == "FETCH_SIZE" else "write") + "_kb_total"] = v
                     rec["tree_launches"] = n
                 if "k_arr_vec<16, true>" in k:
