@@ -1901,20 +1901,35 @@ using KF50P = KF<50, 0, -1>;
 using KF50B = KF<50, 1, -1>;
 using KF254P = KF<254, 0, -1>;
 using KF254B = KF<254, 1, -1>;
+// ... with the criterion of the standard pipelines as a compile-time constant (the decision becomes straight-line
+// code): diameter for `fit`, tolerance-diameter for refinement / merge rounds (packed singleton runs and buffers)
+using KF50PD = KF<50, 0, BBH_CRIT_DIAMETER>;
+using KF50PT = KF<50, 0, BBH_CRIT_TOL_DIAMETER>;
+using KF50BT = KF<50, 1, BBH_CRIT_TOL_DIAMETER>;
+using KF254PD = KF<254, 0, BBH_CRIT_DIAMETER>;
+using KF254PT = KF<254, 0, BBH_CRIT_TOL_DIAMETER>;
+using KF254BT = KF<254, 1, BBH_CRIT_TOL_DIAMETER>;
 
 // Kernel instances by (branching factor, element kind): one table instead of a ladder of launch statements.  Shapes
 // without an entry run the complete engine with the shape as run-time values (k_tree_insert<.., KC>).
 struct FastKernel {
     int bf;
     bool buffers;
+    int crit;  // -1: any of the criteria the steady-state kernel knows, read at run time
     void (*fn)(TreeDev*);
     uint32_t lds;
 };
-static const FastKernel kFastKernels[] = {
-    {50, false, k_tree_fast<KF50P>, fast_layout(50).total},
-    {50, true, k_tree_fast<KF50B>, fast_layout(50).total},
-    {254, false, k_tree_fast<KF254P>, fast_layout(254).total},
-    {254, true, k_tree_fast<KF254B>, fast_layout(254).total},
+static const FastKernel kFastKernels[] = {  // (most specific first)
+    {50, false, BBH_CRIT_DIAMETER, k_tree_fast<KF50PD>, fast_layout(50).total},
+    {50, false, BBH_CRIT_TOL_DIAMETER, k_tree_fast<KF50PT>, fast_layout(50).total},
+    {50, true, BBH_CRIT_TOL_DIAMETER, k_tree_fast<KF50BT>, fast_layout(50).total},
+    {254, false, BBH_CRIT_DIAMETER, k_tree_fast<KF254PD>, fast_layout(254).total},
+    {254, false, BBH_CRIT_TOL_DIAMETER, k_tree_fast<KF254PT>, fast_layout(254).total},
+    {254, true, BBH_CRIT_TOL_DIAMETER, k_tree_fast<KF254BT>, fast_layout(254).total},
+    {50, false, -1, k_tree_fast<KF50P>, fast_layout(50).total},
+    {50, true, -1, k_tree_fast<KF50B>, fast_layout(50).total},
+    {254, false, -1, k_tree_fast<KF254P>, fast_layout(254).total},
+    {254, true, -1, k_tree_fast<KF254B>, fast_layout(254).total},
 };
 
 // uint8 BitFeature buffers with n_samples == 1 are plain fingerprints in unpacked form (ls in {0, 1}):
@@ -2350,9 +2365,11 @@ int run_insert_multi(std::vector<Job>& jobs, hipStream_t s) {
             static const bool no_fast = getenv("BBHIP_NO_FAST") != nullptr;
             bool fast_ok = !no_fast && (all50 || all254);
             bool f_packed = true, f_buffers = true;
+            int f_crit = active.empty() ? -1 : jobs[active[0]].t->h.crit;  // the criterion all trees share, or -1
             for (size_t a = 0; a < active.size() && fast_ok; ++a) {
                 const Job& fj = jobs[active[a]];
                 const int c = fj.t->h.crit;
+                if (c != f_crit) f_crit = -1;
                 fast_ok = c == BBH_CRIT_DIAMETER || c == BBH_CRIT_TOL_DIAMETER || c == BBH_CRIT_TOL_LEGACY || c == BBH_CRIT_NEVER;
                 f_packed = f_packed && fj.bufs == nullptr;
                 f_buffers = f_buffers && fj.bufs != nullptr;
@@ -2363,7 +2380,7 @@ int run_insert_multi(std::vector<Job>& jobs, hipStream_t s) {
             const FastKernel* fk = nullptr;
             if (fast_ok)
                 for (const FastKernel& c : kFastKernels)
-                    if (c.bf == (all50 ? 50 : 254) && c.buffers == f_buffers) fk = &c;
+                    if (fk == nullptr && c.bf == (all50 ? 50 : 254) && c.buffers == f_buffers && (c.crit == -1 || c.crit == f_crit)) fk = &c;
             const dim3 grid((unsigned)active.size()), block(TB);
             if (fk != nullptr && prof_phases && all50 && f_packed) {
                 hipLaunchKernelGGL((k_tree_fast<KF50P, true>), grid, block, fk->lds, s, dptr);

@@ -245,13 +245,15 @@ def parse() -> argparse.Namespace:
     ap.add_argument("--k1-rows", type=int, default=8_000_000)
     ap.add_argument("--shards", type=int, default=512)
     ap.add_argument("--multiround-files", type=int, default=64, help="0 skips the file-based multiround run")
+    ap.add_argument("--distributed", action="store_true",
+                    help="time the one-rank-per-GPU multiround path even at N=1 (what N>1 always times)")
     return ap.parse_args()
 
 
 def main() -> None:
     args = parse()
     env_world = os.environ.get("WORLD_SIZE")
-    if env_world is None and args.gpus > 1:
+    if env_world is None and (args.gpus > 1 or args.distributed):
         # `python bench.py --gpus N` run bare: N ranks of this same script, one per GPU
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
                "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(Path(__file__).resolve())] + sys.argv[1:]
@@ -265,7 +267,7 @@ def main() -> None:
         args.threshold = WORKLOADS[args.workload][1]
     if args.n_fps is None:
         args.n_fps = 1_000_000 if world == 1 else 250_000
-    if world == 1:
+    if world == 1 and not args.distributed:
         single_gpu(args)
     else:
         multi_gpu(args, world)
