@@ -95,6 +95,23 @@ def test_hip_device_resident_input():
     assert a.get_cluster_mol_ids() == b.get_cluster_mol_ids()
 
 
+@pytest.mark.parametrize("row_bytes", [272, 260])
+def test_hip_device_resident_strided_rows(row_bytes):
+    r"""Device-resident rows inside a wider allocation: a 16-byte aligned stride stays on the steady-state kernel
+    (rows are read with 16-byte loads straight into registers), any other stride takes the complete engine."""
+    import torch
+
+    fps = make_fake_fingerprints(6000, seed=4243)
+    wide = torch.zeros((6000, row_bytes), dtype=torch.uint8, device="cuda")
+    wide[:, :256] = torch.from_numpy(fps).cuda()
+    view = wide[:, :256]
+    assert view.stride(0) == row_bytes
+    a = BitBirch(branching_factor=50, threshold=0.3).fit(view)
+    b = BitBirch(branching_factor=50, threshold=0.3, _engine_factory=OracleEngine).fit(fps)
+    assert a.get_cluster_mol_ids() == b.get_cluster_mol_ids()
+    assert a._engine.stats()[:7].tolist() == b._engine.stats()[:7].tolist()
+
+
 def test_hip_edge_cases():
     with pytest.raises(ValueError):
         BitBirch().fit(np.zeros((0, 256), dtype=np.uint8), n_features=2048)
