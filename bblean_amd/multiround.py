@@ -161,6 +161,29 @@ def _merge_rounds(
     return trees
 
 
+def _merge_one_tree_streaming(
+    pairs: tp.Sequence[tuple[Path, Path]], *, branching_factor: int, threshold: float, tolerance: float, criterion: str,
+    engine_factory: tp.Any, device: int,
+) -> BitBirch:
+    r"""`_FinalTreeMergingRound` (multiround.py:284-312): one tree, the round files of the previous round in name order.
+    The next file pair is read (un-pickling the member lists is most of it) by a helper thread while the device
+    inserts the current one - the C calls release the GIL."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    tree = BitBirch(branching_factor=branching_factor, threshold=threshold, merge_criterion=criterion,
+                    tolerance=tolerance, device=device, _engine_factory=engine_factory)
+    if pairs:
+        with ThreadPoolExecutor(max_workers=1) as ex:
+            fut = ex.submit(_load_pair, *pairs[0])
+            for i in range(len(pairs)):
+                bufs, idx = fut.result()
+                if i + 1 < len(pairs):
+                    fut = ex.submit(_load_pair, *pairs[i + 1])
+                tree._fit_buffers(bufs, idx)
+    tree.delete_internal_nodes()
+    return tree
+
+
 def _save_tables(out_dir: Path, bufs: dict, mols: dict, label: str, round_idx: int) -> None:
     r"""`_save_bufs_and_mol_idxs` (multiround.py:132-143): same names, same bytes."""
     for name, table in bufs.items():
@@ -260,8 +283,8 @@ def run_multiround_bitbirch(
 
     round_idx += 1
     timer.init_timing(f"round-{round_idx}")
-    tree = _merge_rounds([[_load_pair(*p) for p in prev_pairs(round_idx)]],
-                         threshold=threshold + midsection_threshold_change, criterion=final_merge_criterion, **common)[0]
+    tree = _merge_one_tree_streaming(prev_pairs(round_idx), threshold=threshold + midsection_threshold_change,
+                                     criterion=final_merge_criterion, **common)
     if save_tree:
         raise NotImplementedError("whole-tree pickling is not provided (the reference's --save-tree is broken too)")
     _write_outputs(out_dir, tree, save_centroids)
