@@ -73,6 +73,27 @@ def test_hip_tree_vs_oracle_large(crit, thr, bf, n, kind):
     assert s_h[:7].tolist() == s_o[:7].tolist()  # same comparisons, merges, appends, splits
 
 
+@pytest.mark.parametrize("crit,thr,tol", [("diameter", 0.3, None), ("radius", 0.35, None), ("never-merge", 0.3, 0.05),
+                                          ("tolerance-diameter", 0.3, 0.05), ("tolerance-radius", 0.3, 0.05),
+                                          ("tolerance-legacy", 0.3, 0.05)])
+def test_hip_per_insert_trace_vs_oracle(crit, thr, tol):
+    r"""the insertion trace, element by element.  `out_leaf[e]` is the leaf BitFeature element e
+    ended in at the moment it was inserted (a fresh id = appended, an existing id = merged), and the engine counters
+    (descent calls, rows compared, merges, appends, leaf / node / root splits) are compared after every 250
+    insertions - a descent that took another child, a different merge decision or a split at another element shows
+    up in the chunk where it happens, not only in the final clusters."""
+    fps = make_fake_fingerprints(3000, seed=77, pack=True)
+    kw = dict(branching_factor=8, threshold=thr, merge_criterion=crit)
+    if tol is not None:
+        kw["tolerance"] = tol
+    hip, ora = BitBirch(**kw), BitBirch(_engine_factory=OracleEngine, **kw)
+    for lo in range(0, 3000, 250):
+        hip.fit(fps[lo:lo + 250])
+        ora.fit(fps[lo:lo + 250])
+        assert (hip._log_leaf[-1] == ora._log_leaf[-1]).all(), lo
+        assert hip._engine.stats()[:7].tolist() == ora._engine.stats()[:7].tolist(), lo
+
+
 def test_hip_refine_pipeline_vs_oracle():
     r"""config[2] shape at test scale: fit, then refine with tolerance-diameter."""
     fps = np.concatenate([make_fake_fingerprints(10_000, seed=900 + i) for i in range(3)])
