@@ -1951,6 +1951,12 @@ __global__ __launch_bounds__(256) void k_pack_singletons(const uint8_t* __restri
     out[i] = (uint8_t)byte;
 }
 
+// the n_samples column of a uint8 BitFeature table, contiguous (the host decides on it where singleton runs start)
+__global__ __launch_bounds__(256) void k_gather_n_col(const uint8_t* __restrict__ bufs, long long k, int F, uint8_t* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < k) out[i] = bufs[(size_t)i * ((size_t)F + 1) + (size_t)F];
+}
+
 // =======================================================================================
 // Batch mode (exact, rollback-free): a prefix of the pending fingerprints is routed through the
 // STABLE upper levels of the tree in parallel (k_route), the host admits the longest prefix for
@@ -2730,8 +2736,17 @@ extern "C" int bbh_tree_fit_buffers(bbh_tree* t, const void* bufs, int32_t width
     const bool split_runs = width == 1 && !no_singleton_path;
     if (bb::is_device_ptr(bufs)) {
         if (split_runs) {
-            std::vector<uint8_t> n_col((size_t)k);  // the n_samples column: one strided copy
-            BB_HIP(hipMemcpy2D(n_col.data(), 1, (const uint8_t*)bufs + t->h.F, row_bytes, 1, (size_t)k, hipMemcpyDeviceToHost));
+            // the n_samples column: gathered on the device, one contiguous copy (a 1-byte-wide hipMemcpy2D over
+            // 360 k rows took half a second)
+            std::vector<uint8_t> n_col((size_t)k);
+            uint8_t* col = nullptr;
+            BB_HIP(bb::dev_alloc(&col, (size_t)k));
+            hipLaunchKernelGGL(k_gather_n_col, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, s, (const uint8_t*)bufs, (long long)k,
+                               t->h.F, col);
+            hipError_t ce = hipMemcpyAsync(n_col.data(), col, (size_t)k, hipMemcpyDeviceToHost, s);
+            if (ce == hipSuccess) ce = hipStreamSynchronize(s);
+            (void)bb::dev_free(col);
+            BB_HIP(ce);
             BB_TRY(insert_u8_buffers(t, (const uint8_t*)bufs, k, n_col.data(), (uint32_t*)o.dev, s));
         } else {
             BB_TRY(run_insert(t, nullptr, 0, (const uint8_t*)bufs, width, k, (uint32_t*)o.dev, s));
