@@ -10,6 +10,7 @@ with NumPy exactly as `_merges.py:82-116` does, so the device never calls ``exp`
 from __future__ import annotations
 
 import dataclasses
+import functools
 
 import numpy as np
 from numpy.typing import NDArray
@@ -67,11 +68,7 @@ class MergeCriterion:
         reference's max(..., 0.0) clamps every later entry, _merges.py:113)."""
         if self.name not in _ADAPTIVE or self._tolerance is None:
             return np.zeros(0, dtype=np.float64)
-        offset = np.exp(-self.decay * self.n_max)
-        out = np.empty(self.n_max + 1, dtype=np.float64)
-        for old_n in range(self.n_max + 1):
-            out[old_n] = max(self._tolerance * (np.exp(-self.decay * old_n) - offset), 0.0)
-        return out
+        return _tolerance_table(float(self._tolerance), float(self.decay), int(self.n_max))
 
     def __repr__(self) -> str:
         cls = {
@@ -85,6 +82,18 @@ class MergeCriterion:
         if self.name in ("tolerance-diameter", "tolerance-radius", "tolerance-legacy"):
             return f"{cls}({self._tolerance})"
         return f"{cls}()"
+
+
+@functools.lru_cache(maxsize=64)
+def _tolerance_table(tolerance: float, decay: float, n_max: int) -> NDArray[np.float64]:
+    # scalar np.exp per entry, as the reference evaluates it (a vectorised exp may round differently); every tree of
+    # a multiround run asks for the same table, hence the cache
+    offset = np.exp(-decay * n_max)
+    out = np.empty(n_max + 1, dtype=np.float64)
+    for old_n in range(n_max + 1):
+        out[old_n] = max(tolerance * (np.exp(-decay * old_n) - offset), 0.0)
+    out.setflags(write=False)
+    return out
 
 
 def get_merge_accept_fn(merge_criterion: str, tolerance: float = 0.05) -> MergeCriterion:

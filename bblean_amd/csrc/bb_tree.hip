@@ -40,6 +40,8 @@
 // ingest of host / file-backed rows (HostSlabs) and the leaf export kernels.
 #include "bb_common.h"
 
+#include <chrono>
+
 #include <algorithm>
 #include <cmath>
 #include <future>
@@ -2353,6 +2355,13 @@ int run_insert_multi(std::vector<Job>& jobs, hipStream_t s) {
         }
         TreeDev* dptr = single ? jobs[0].t->d : darr;
         size_t prof_tok = (size_t)-1;
+        static const bool launch_log = getenv("BBHIP_LAUNCH_LOG") != nullptr;  // one line per launch on stderr (tools/)
+        const auto log_t0 = std::chrono::steady_clock::now();
+        const char* log_kernel = "complete";
+        uint64_t log_before[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (launch_log)
+            for (size_t a = 0; a < active.size(); ++a)
+                for (int z = 0; z < 8; ++z) log_before[z] += jobs[active[a]].t->h.stats[z];
         hipError_t e = hipMemcpyAsync(dptr, harr.data(), active.size() * sizeof(TreeDev), hipMemcpyHostToDevice, s);
         if (e != hipSuccess) { rc = bb::fail(BBH_ERR_HIP, "H2D: %s", hipGetErrorString(e)); break; }
         {
@@ -2391,6 +2400,7 @@ int run_insert_multi(std::vector<Job>& jobs, hipStream_t s) {
             if (fk != nullptr && prof_phases && all50 && f_packed) {
                 hipLaunchKernelGGL((k_tree_fast<KF50P, true>), grid, block, fk->lds, s, dptr);
             } else if (fk != nullptr) {
+                log_kernel = "fast";
                 hipLaunchKernelGGL(fk->fn, grid, block, fk->lds, s, dptr);
             } else if (prof_phases) {
                 const uint32_t* const nu = nullptr;
@@ -2407,6 +2417,22 @@ int run_insert_multi(std::vector<Job>& jobs, hipStream_t s) {
         if (e == hipSuccess) e = hipMemcpyAsync(harr.data(), dptr, active.size() * sizeof(TreeDev), hipMemcpyDeviceToHost, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);
         if (e != hipSuccess) { rc = bb::fail(BBH_ERR_HIP, "tree_insert: %s", hipGetErrorString(e)); break; }
+        if (launch_log) {
+            const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - log_t0).count();
+            uint64_t after[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            long long done = 0;
+            for (size_t a = 0; a < active.size(); ++a) {
+                for (int z = 0; z < 8; ++z) after[z] += harr[a].stats[z];
+                done += harr[a].processed;
+            }
+            const Job& j0 = jobs[active[0]];
+            fprintf(stderr, "[bbhip launch] %s trees=%zu %s crit=%d elems=%lld %.2f ms (%.2f us/elem) calls=%llu rows=%llu merges=%llu appends=%llu "
+                    "leaf_splits=%llu node_splits=%llu stop=%d\n", log_kernel, active.size(), j0.bufs ? (j0.width == 1 ? "buf8" : j0.width == 2 ? "buf16" : "buf32+") : "packed",
+                    j0.t->h.crit, done, ms, done ? 1e3 * ms / (double)done : 0.0, (unsigned long long)(after[0] - log_before[0]),
+                    (unsigned long long)(after[1] - log_before[1]), (unsigned long long)(after[2] - log_before[2]),
+                    (unsigned long long)(after[3] - log_before[3]), (unsigned long long)(after[4] - log_before[4]),
+                    (unsigned long long)(after[5] - log_before[5]), harr[0].stop_reason);
+        }
         for (size_t a = 0; a < active.size() && rc == BBH_OK; ++a) {
             Job& j = jobs[active[a]];
             bbh_tree* t = j.t;

@@ -65,4 +65,4 @@ with tempfile.TemporaryDirectory() as d:
     dt = time.perf_counter() - t0
     pr.disable()
 print(f"total {dt:.2f}s", {k: round(v, 3) for k, v in timer.timings.items()})
-pstats.Stats(pr).sort_stats("cumulative").print_stats(22)
+pstats.Stats(pr).sort_stats("cumulative").print_stats(60)
