@@ -2398,6 +2398,7 @@ int run_insert_multi(std::vector<Job>& jobs, hipStream_t s) {
                     if (fk == nullptr && c.bf == (all50 ? 50 : 254) && c.buffers == f_buffers && (c.crit == -1 || c.crit == f_crit)) fk = &c;
             const dim3 grid((unsigned)active.size()), block(TB);
             if (fk != nullptr && prof_phases && all50 && f_packed) {
+                log_kernel = "fast+phases";
                 hipLaunchKernelGGL((k_tree_fast<KF50P, true>), grid, block, fk->lds, s, dptr);
             } else if (fk != nullptr) {
                 log_kernel = "fast";

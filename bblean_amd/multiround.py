@@ -296,14 +296,26 @@ def run_multiround_bitbirch(
     return timer
 
 
+class _RowsAsList:
+    r"""Pickles a 2-D array as ONE block that un-pickles (with nothing but NumPy installed) to ``list(array)``: the list
+    of per-cluster centroid arrays the reference writes (multiround.py:308-309), without 360 k separate array reductions
+    (1.4 s per million-row run; the block takes 30 ms)."""
+
+    def __init__(self, rows: NDArray[np.uint8]) -> None:
+        self.rows = rows
+
+    def __reduce__(self) -> tuple[tp.Any, tuple[tp.Any]]:
+        return (list, (np.ascontiguousarray(self.rows),))
+
+
 def _write_outputs(out_dir: Path, tree: BitBirch, save_centroids: bool) -> None:
     r"""clusters.pkl / cluster-centroids-packed.pkl (multiround.py:303-312)."""
     if save_centroids:
-        out = tree.get_centroids_mol_ids()
+        order = tree._leaf_order(True)
         with open(out_dir / "clusters.pkl", "wb") as f:
-            pickle.dump(out["mol_ids"], f)
+            pickle.dump(tree._members_of(order), f)
         with open(out_dir / "cluster-centroids-packed.pkl", "wb") as f:
-            pickle.dump(out["centroids"], f)
+            pickle.dump(_RowsAsList(tree._leaves()["cents"][order]), f)
     else:
         with open(out_dir / "clusters.pkl", "wb") as f:
             pickle.dump(tree.get_cluster_mol_ids(), f)
