@@ -2286,6 +2286,7 @@ int configure(bbh_tree* t, int32_t bf, int32_t n_features) {
             for (const FastKernel& fk : kFastKernels)
                 BB_HIP(hipFuncSetAttribute((const void*)fk.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fk.lds));
             BB_HIP(hipFuncSetAttribute((const void*)k_tree_fast<KF50P, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast_layout(50).total));
+            BB_HIP(hipFuncSetAttribute((const void*)k_tree_fast<KF254P, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast_layout(254).total));
             fast_attr_done = true;
         }
     }
@@ -2397,9 +2398,10 @@ int run_insert_multi(std::vector<Job>& jobs, hipStream_t s) {
                 for (const FastKernel& c : kFastKernels)
                     if (fk == nullptr && c.bf == (all50 ? 50 : 254) && c.buffers == f_buffers && (c.crit == -1 || c.crit == f_crit)) fk = &c;
             const dim3 grid((unsigned)active.size()), block(TB);
-            if (fk != nullptr && prof_phases && all50 && f_packed) {
+            if (fk != nullptr && prof_phases && f_packed) {
                 log_kernel = "fast+phases";
-                hipLaunchKernelGGL((k_tree_fast<KF50P, true>), grid, block, fk->lds, s, dptr);
+                if (all50) hipLaunchKernelGGL((k_tree_fast<KF50P, true>), grid, block, fk->lds, s, dptr);
+                else hipLaunchKernelGGL((k_tree_fast<KF254P, true>), grid, block, fk->lds, s, dptr);
             } else if (fk != nullptr) {
                 log_kernel = "fast";
                 hipLaunchKernelGGL(fk->fn, grid, block, fk->lds, s, dptr);

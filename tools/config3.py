@@ -1,8 +1,9 @@
 """BASELINE.json configs[2]: S-ecfp(N) (sparse ECFP4-like rows around N/50 planted prototypes,
-SURVEY.md section 8d), threshold 0.3, bf 50, `bb run --refine-num 1` sequence (cli.py:1067-1092):
+SURVEY.md section 8d), threshold 0.3, `bb run --refine-num 1` sequence (cli.py:1067-1092) with the CLI's default
+branching factor 254 (or the one given):
 fit -> set_merge(tolerance-diameter, tol 0.05) -> refine_inplace(n_largest=1).
 
-    python tools/config3.py N [check_n]
+    python tools/config3.py N [check_n] [branching_factor]
 
 Times the HIP engine on N rows; when check_n > 0 the first check_n rows are also run through
 the CPU oracle with the same host logic and the cluster ids compared."""
@@ -12,6 +13,8 @@ import time
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
 import numpy as np
 import torch
+
+BF = int(sys.argv[3]) if len(sys.argv) > 3 else 254
 
 
 def synth_ecfp(n: int, seed: int, device, n_features: int = 2048):
@@ -57,7 +60,7 @@ def run(fps, host, engine_factory=None):
     lib.bbh_profile_reset()
     kw = {} if engine_factory is None else {"_engine_factory": engine_factory}
     t0 = time.perf_counter()
-    tree = BitBirch(branching_factor=50, threshold=0.3, merge_criterion="diameter", **kw)
+    tree = BitBirch(branching_factor=BF, threshold=0.3, merge_criterion="diameter", **kw)
     tree.fit(fps)
     t1 = time.perf_counter()
     k_fit = len(tree._leaves()["ids"])
