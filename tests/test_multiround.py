@@ -45,7 +45,11 @@ def _run_files(case: dict, engine_factory) -> None:
         (d / "out").mkdir()
         run_multiround_bitbirch(files, d / "out", num_initial_processes=1, _engine_factory=engine_factory, **case["kwargs"])
         clusters = pickle.load(open(d / "out" / "clusters.pkl", "rb"))
-        cents = pickle.load(open(d / "out" / "cluster-centroids-packed.pkl", "rb"))
+        raw = (d / "out" / "cluster-centroids-packed.pkl").read_bytes()
+        cents = pickle.loads(raw)
+        # the reference's shape of that file: a plain list of uint8 arrays, loadable with NumPy alone
+        assert type(cents) is list and all(type(c) is np.ndarray and c.dtype == np.uint8 and c.ndim == 1 for c in cents)
+        assert b"bblean" not in raw
         assert not list((d / "out").glob("round-*"))  # cleanup like the reference
     _check(case, clusters, cents)
 
