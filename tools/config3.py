@@ -14,7 +14,7 @@ sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
 import numpy as np
 import torch
 
-BF = int(sys.argv[3]) if len(sys.argv) > 3 else 254
+BF = 254  # the CLI's default; main() takes another one from the command line
 
 
 def synth_ecfp(n: int, seed: int, device, n_features: int = 2048):
@@ -77,8 +77,10 @@ def run(fps, host, engine_factory=None):
 
 
 def main():
+    global BF
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
     check_n = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    BF = int(sys.argv[3]) if len(sys.argv) > 3 else BF
     dev = torch.device("cuda")
     fps = synth_ecfp(n, 7, dev)
     torch.cuda.synchronize()
