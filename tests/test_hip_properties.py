@@ -75,14 +75,15 @@ def test_properties_config2_1M_fake():
     assert np.array_equal(tree.get_assignments(), again.get_assignments())
 
 
-def test_properties_config3_2M_sparse_with_refine():
+@pytest.mark.parametrize("bf", [254, 50])  # 254: the default of `bb run`, i.e. BASELINE config 3 as the CLI runs it
+def test_properties_config3_2M_sparse_with_refine(bf):
     import torch
 
     from config3 import synth_ecfp
 
     fps = synth_ecfp(2_000_000, 11, torch.device("cuda"))
     host = fps.cpu().numpy()
-    tree = BitBirch(branching_factor=50, threshold=0.3).fit(fps)
+    tree = BitBirch(branching_factor=bf, threshold=0.3).fit(fps)
     _check_tree(tree, host, sample=100, seed=2)
     tree.set_merge("tolerance-diameter", tolerance=0.05, threshold=0.3)
     tree.refine_inplace(host, n_largest=1)
