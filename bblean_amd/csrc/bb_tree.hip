@@ -477,9 +477,12 @@ __device__ __forceinline__ uint32_t centroid_byte(const uint32_t v[8], u64 n) {
 __device__ __forceinline__ uint32_t centroid_byte_merged(const uint32_t v[8], u64 n) {
     uint32_t byte = 0;
     if (n <= 0x7FFFFFFFull) {
-        const uint32_t half = (uint32_t)((n + 1) >> 1);
+        // v >= ceil(n/2)  <=>  (ceil(n/2) - 1) - v is negative as int32 (v <= n < 2^31): its sign bit is the centroid
+        // bit, shifted in from the right - two instructions per feature (v_sub, v_alignbit) instead of compare,
+        // select and or
+        const uint32_t hm1 = (uint32_t)((n + 1) >> 1) - 1u;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) byte |= (v[q] >= half ? 1u : 0u) << (7 - q);
+        for (int q = 0; q < 8; ++q) byte = __builtin_amdgcn_alignbit(byte, hm1 - v[q], 31);
     } else {
 #pragma unroll
         for (int q = 0; q < 8; ++q) byte |= (2ull * v[q] >= n ? 1u : 0u) << (7 - q);
