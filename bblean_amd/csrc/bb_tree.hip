@@ -411,6 +411,16 @@ __device__ __forceinline__ void cf_store8(const KCt& k, uint32_t slotw, int b, c
     }
 }
 
+// a BitFeature known to be in the uint8 tier (a freshly appended one): no tier dispatch
+template <class KCt>
+__device__ __forceinline__ void cf_store8_u8(const KCt& k, uint32_t slot, int b, const uint32_t v[8]) {
+    const size_t idx = (size_t)slot * (size_t)k.F + (size_t)b * 8;
+    u32x2_t q;
+    q.x = v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);
+    q.y = v[4] | (v[5] << 8) | (v[6] << 16) | (v[7] << 24);
+    stg<u32x2_t>(k.cf8 + idx, q);
+}
+
 // tracking BitFeatures always live in cf32: no tier dispatch on the hot path
 template <class KCt>
 __device__ __forceinline__ void cf32_load8(const KCt& k, uint32_t slotw, int b, uint32_t v[8]) {
