@@ -500,6 +500,16 @@ __device__ __forceinline__ uint32_t centroid_byte_merged(const uint32_t v[8], u6
     return byte;
 }
 
+// the same for n < 2^31 only (the steady-state kernel leaves larger clusters to the complete engine): no 64-bit variant,
+// i.e. no branch on a value the compiler has to treat as divergent
+__device__ __forceinline__ uint32_t centroid_byte_merged31(const uint32_t v[8], uint32_t n) {
+    const uint32_t hm1 = ((n + 1u) >> 1) - 1u;
+    uint32_t byte = 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) byte = __builtin_amdgcn_alignbit(byte, hm1 - v[q], 31);
+    return byte;
+}
+
 __device__ __forceinline__ uint32_t tier_for(u64 n) { return n <= 255 ? 0u : (n <= 65535 ? 1u : 2u); }
 __device__ __forceinline__ int ctr_for_tier(uint32_t tier) { return tier == 0 ? C_N8 : (tier == 1 ? C_N16 : C_N32); }
 
