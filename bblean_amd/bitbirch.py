@@ -111,9 +111,9 @@ class _IndexLists:
         return int(self.counts.size)
 
     def to_lists(self) -> list[list[int]]:
-        offs = np.concatenate(([0], np.cumsum(self.counts)))
+        offs = np.concatenate(([0], np.cumsum(self.counts))).tolist()  # (Python ints: indexing an array per cluster costs more)
         flat = self.flat.tolist()
-        return [flat[offs[i] : offs[i + 1]] for i in range(len(self))]
+        return [flat[a:b] for a, b in zip(offs[:-1], offs[1:])]
 
 
 class _LeafBF:
