@@ -745,4 +745,37 @@ void bbo_tree_export_leaves(const bbo_tree* t, uint32_t* leaf_ids, uint64_t* n_s
     }
 }
 
+/* BitFeature buffer rows [linear sum (n_features values), n_samples] of the leaves at `positions` (indices into the
+ * leaf-chain order of bbo_tree_export_leaves), `width` bytes per value: what _bf_to_np writes (reference
+ * bitbirch.py:1224-1290), without exporting every leaf at 4 bytes per feature first. */
+int bbo_tree_gather_buffers(const bbo_tree* t, const int64_t* positions, int64_t m, int32_t width, void* out) {
+    int64_t k = 0;
+    for (const Node* nd = t->first_leaf; nd; nd = nd->next_leaf) k += nd->len;
+    const Sub** subs = (const Sub**)malloc((size_t)(k > 0 ? k : 1) * sizeof(*subs));
+    if (!subs) return 1;
+    k = 0;
+    for (const Node* nd = t->first_leaf; nd; nd = nd->next_leaf)
+        for (int i = 0; i < nd->len; ++i) subs[k++] = nd->subs[i];
+    const size_t cols = (size_t)t->F + 1;
+    int rc = 0;
+    for (int64_t r = 0; r < m && rc == 0; ++r) {
+        const int64_t p = positions[r];
+        if (p < 0 || p >= k) { rc = 2; break; }
+        const Sub* s = subs[p];
+        for (size_t j = 0; j < cols; ++j) {
+            const uint64_t v = j < (size_t)t->F ? (uint64_t)sub_ls(s, (int)j) : (uint64_t)s->n;
+            const size_t at = (size_t)r * cols + j;
+            switch (width) {
+                case 1: ((uint8_t*)out)[at] = (uint8_t)v; break;
+                case 2: ((uint16_t*)out)[at] = (uint16_t)v; break;
+                case 4: ((uint32_t*)out)[at] = (uint32_t)v; break;
+                case 8: ((uint64_t*)out)[at] = v; break;
+                default: rc = 3; break;
+            }
+        }
+    }
+    free(subs);
+    return rc;
+}
+
 void bbo_tree_stats(const bbo_tree* t, uint64_t* out7) { memcpy(out7, t->stats, sizeof(t->stats)); }

@@ -96,6 +96,9 @@ int64_t bbo_tree_leaf_count(const bbo_tree* t);
  * linear_sums: k x n_features uint32. */
 void bbo_tree_export_leaves(const bbo_tree* t, uint32_t* leaf_ids, uint64_t* n_samples,
                             uint8_t* packed_centroids, uint32_t* linear_sums);
+/* BitFeature buffer rows [linear sum, n_samples] of the leaves at `positions` (indices into that order), `width`
+ * (1, 2, 4 or 8) bytes per value; 0 on success. */
+int bbo_tree_gather_buffers(const bbo_tree* t, const int64_t* positions, int64_t m, int32_t width, void* out);
 /* counters: [0]=similarity calls, [1]=rows compared, [2]=merges, [3]=appends,
  * [4]=splits, [5]=nodes, [6]=max depth seen */
 void bbo_tree_stats(const bbo_tree* t, uint64_t* out7);

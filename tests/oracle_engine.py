@@ -43,6 +43,7 @@ def oracle_lib() -> C.CDLL:
         "bbo_tree_fit_buffers": (C.c_int, [vp, vp, i32, i64, vp]),
         "bbo_tree_leaf_count": (i64, [vp]),
         "bbo_tree_export_leaves": (None, [vp, vp, vp, vp, vp]),
+        "bbo_tree_gather_buffers": (C.c_int, [vp, vp, i64, i32, vp]),
         "bbo_tree_stats": (None, [vp, vp]),
     }
     for name, (res, args) in protos.items():
@@ -107,11 +108,10 @@ class OracleEngine:
         return ids, ns, cents, ls
 
     def gather_buffers(self, positions, width):
-        ids, ns, cents, ls = self.export_leaves(4)
-        pos = np.asarray(positions, dtype=np.int64)
+        pos = np.ascontiguousarray(positions, dtype=np.int64)
         out = np.empty((pos.size, self.n_features + 1), dtype=_W[width])
-        out[:, :-1] = ls[pos]
-        out[:, -1] = ns[pos]
+        rc = self.lib.bbo_tree_gather_buffers(self._h, pos.ctypes.data, pos.size, int(width), out.ctypes.data)
+        assert rc == 0, rc
         return out
 
     def stats(self):
