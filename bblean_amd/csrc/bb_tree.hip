@@ -1916,6 +1916,7 @@ __global__ __launch_bounds__(TB, 2) void k_tree_insert_dense(TreeDev* trees) {
 
 #endif  // __HIPCC__ (bb_tree_fast.inc has its own host / device split)
 #include "bb_tree_fast.inc"
+#include "bb_tree_pipe.inc"
 #if defined(__HIPCC__)
 
 // the complete engine compiled for the benchmark shape with phase timers (tools/phases.py with BBHIP_NO_FAST=1)
@@ -1955,6 +1956,19 @@ static const FastKernel kFastKernels[] = {  // (most specific first)
     {50, true, -1, k_tree_fast<KF50B>, fast_layout(50).total},
     {254, false, -1, k_tree_fast<KF254P>, fast_layout(254).total},
     {254, true, -1, k_tree_fast<KF254B>, fast_layout(254).total},
+};
+
+// the pipelined kernel (bb_tree_pipe.inc): packed fingerprints, one tree per launch, diameter / tolerance-diameter
+struct PipeKernel {
+    int bf, crit;
+    void (*fn)(TreeDev*);
+    uint32_t lds;
+};
+static const PipeKernel kPipeKernels[] = {
+    {50, BBH_CRIT_DIAMETER, k_tree_pipe<KP<50, BBH_CRIT_DIAMETER>>, pipe_layout(50).total},
+    {50, BBH_CRIT_TOL_DIAMETER, k_tree_pipe<KP<50, BBH_CRIT_TOL_DIAMETER>>, pipe_layout(50).total},
+    {254, BBH_CRIT_DIAMETER, k_tree_pipe<KP<254, BBH_CRIT_DIAMETER>>, pipe_layout(254).total},
+    {254, BBH_CRIT_TOL_DIAMETER, k_tree_pipe<KP<254, BBH_CRIT_TOL_DIAMETER>>, pipe_layout(254).total},
 };
 
 // uint8 BitFeature buffers with n_samples == 1 are plain fingerprints in unpacked form (ls in {0, 1}):
@@ -2310,6 +2324,8 @@ int configure(bbh_tree* t, int32_t bf, int32_t n_features) {
                 BB_HIP(hipFuncSetAttribute((const void*)fk.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fk.lds));
             BB_HIP(hipFuncSetAttribute((const void*)k_tree_fast<KF50P, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast_layout(50).total));
             BB_HIP(hipFuncSetAttribute((const void*)k_tree_fast<KF254P, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast_layout(254).total));
+            for (const PipeKernel& pk : kPipeKernels)
+                BB_HIP(hipFuncSetAttribute((const void*)pk.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pk.lds));
             fast_attr_done = true;
         }
     }
@@ -2332,6 +2348,8 @@ static bool dense_launch(size_t n_trees, size_t lds_bytes) {
     return n_trees > (size_t)cus && 2 * lds_bytes <= 160 * 1024;
 }
 
+uint32_t clamp30(uint64_t v) { return (uint32_t)std::min<uint64_t>(0x3FFFFFFFull, v); }
+
 // One insertion job: a tree and the elements to insert into it.
 struct Job {
     bbh_tree* t;
@@ -2343,6 +2361,7 @@ struct Job {
     uint32_t* out;  // device or null
     int64_t done;
     int stalls;
+    int64_t old_left = 0;  // elements the steady-state kernel takes next (the pipelined one reported a shape it does not handle)
 };
 
 // Run the insertion kernel over all jobs, ONE WORKGROUP PER TREE in a single launch (independent
@@ -2373,7 +2392,7 @@ int run_insert_multi(std::vector<Job>& jobs, hipStream_t s) {
             h.row_stride = j.row_stride;
             h.bufs = j.bufs ? j.bufs + (size_t)j.done * ((size_t)h.F + 1) * j.width : nullptr;
             h.width = j.width;
-            h.n_elems = j.n - j.done;
+            h.n_elems = j.old_left > 0 ? std::min<int64_t>(j.old_left, j.n - j.done) : j.n - j.done;
             h.out_leaf = j.out ? j.out + j.done : nullptr;
             harr[a] = h;
         }
@@ -2421,7 +2440,35 @@ int run_insert_multi(std::vector<Job>& jobs, hipStream_t s) {
                 for (const FastKernel& c : kFastKernels)
                     if (fk == nullptr && c.bf == (all50 ? 50 : 254) && c.buffers == f_buffers && (c.crit == -1 || c.crit == f_crit)) fk = &c;
             const dim3 grid((unsigned)active.size()), block(TB);
-            if (fk != nullptr && prof_phases && f_packed) {
+            // the pipelined kernel: one tree, packed rows, the criteria of the standard pipelines
+            static const bool no_pipe = getenv("BBHIP_NO_PIPE") != nullptr;
+            const PipeKernel* pk = nullptr;
+            if (fk != nullptr && !no_pipe && !prof_phases && single && f_packed && jobs[active[0]].old_left == 0 &&
+                harr[0].n_elems < (1ll << 31)) {
+                for (const PipeKernel& c : kPipeKernels)
+                    if (pk == nullptr && c.bf == (all50 ? 50 : 254) && c.crit == f_crit) pk = &c;
+            }
+            if (pk != nullptr) {
+                // tier promotions of elements in flight take cf16 / cf32 slots without asking: keep a reserve
+                bbh_tree* t0 = jobs[active[0]].t;
+                bool grown = false;
+                if (t0->h.cap16 - std::min(t0->h.cap16, t0->h.ctr[C_N16]) < (uint32_t)PROMO_RESERVE) {
+                    rc = grow_cf(t0, 1, clamp30((uint64_t)t0->h.ctr[C_N16] + 2 * PROMO_RESERVE));
+                    grown = true;
+                }
+                if (rc == BBH_OK && t0->h.cap32 - std::min(t0->h.cap32, t0->h.ctr[C_N32]) < (uint32_t)PROMO_RESERVE) {
+                    rc = grow_cf(t0, 2, clamp30((uint64_t)t0->h.ctr[C_N32] + 2 * PROMO_RESERVE));
+                    grown = true;
+                }
+                if (rc != BBH_OK) break;
+                if (grown) {
+                    harr[0].cf16 = t0->h.cf16; harr[0].cf32 = t0->h.cf32; harr[0].cap16 = t0->h.cap16; harr[0].cap32 = t0->h.cap32;
+                    e = hipMemcpyAsync(dptr, harr.data(), sizeof(TreeDev), hipMemcpyHostToDevice, s);
+                    if (e != hipSuccess) { rc = bb::fail(BBH_ERR_HIP, "H2D: %s", hipGetErrorString(e)); break; }
+                }
+                log_kernel = "pipe";
+                hipLaunchKernelGGL(pk->fn, grid, block, pk->lds, s, dptr);
+            } else if (fk != nullptr && prof_phases && f_packed) {
                 log_kernel = "fast+phases";
                 if (all50) hipLaunchKernelGGL((k_tree_fast<KF50P, true>), grid, block, fk->lds, s, dptr);
                 else hipLaunchKernelGGL((k_tree_fast<KF254P, true>), grid, block, fk->lds, s, dptr);
@@ -2469,8 +2516,9 @@ int run_insert_multi(std::vector<Job>& jobs, hipStream_t s) {
             std::memcpy(h.phase, back.phase, sizeof(h.phase));
             std::memcpy(h.sphase, back.sphase, sizeof(h.sphase));
             j.done += back.processed;
+            if (j.old_left > 0) j.old_left = std::max<int64_t>(0, j.old_left - back.processed);
             if (prof_tok != (size_t)-1) bb::prof_units(prof_tok, back.processed);  // elements this launch inserted
-            j.stalls = back.processed == 0 ? j.stalls + 1 : 0;
+            j.stalls = (back.processed == 0 && back.stop_reason != STOP_PIPE_UNSUPPORTED) ? j.stalls + 1 : 0;
             if (j.stalls > 3) { rc = bb::fail(BBH_ERR_CAPACITY, "tree engine made no progress (stop reason %d)", back.stop_reason); break; }
             const int64_t left = j.n - j.done;
             auto more = [&](uint32_t used, uint32_t cap, int64_t per_elem_hint) -> uint32_t {
@@ -2488,6 +2536,8 @@ int run_insert_multi(std::vector<Job>& jobs, hipStream_t s) {
                 case STOP_CF32: rc = grow_cf(t, 2, more(h.ctr[C_N32], h.cap32, 1)); break;
                 case STOP_DEPTH: rc = bb::fail(BBH_ERR_CAPACITY, "tree deeper than %d levels (or corrupt link)", MAXD); break;
                 case STOP_RANGE: rc = bb::fail(BBH_ERR_INVALID, "n_samples exceeds 2^32-1 (engine limit)"); break;
+                case STOP_PIPE_UNSUPPORTED: j.old_left = 8192; break;  // a stretch on the steady-state kernel, then the pipeline again
+                case STOP_INTERNAL: rc = bb::fail(BBH_ERR_HIP, "pipelined kernel: a wait gave up (internal error)"); break;
                 default: rc = bb::fail(BBH_ERR_HIP, "unknown stop reason %d", back.stop_reason); break;
             }
         }
@@ -2503,7 +2553,6 @@ int run_insert(bbh_tree* t, const uint8_t* rows_dev, int64_t row_stride, const u
     return run_insert_multi(jobs, s);
 }
 
-uint32_t clamp30(uint64_t v) { return (uint32_t)std::min<uint64_t>(0x3FFFFFFFull, v); }
 
 #include "bb_tree_batch.inc"
 
