@@ -2326,6 +2326,8 @@ int configure(bbh_tree* t, int32_t bf, int32_t n_features) {
             BB_HIP(hipFuncSetAttribute((const void*)k_tree_fast<KF254P, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast_layout(254).total));
             for (const PipeKernel& pk : kPipeKernels)
                 BB_HIP(hipFuncSetAttribute((const void*)pk.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pk.lds));
+            BB_HIP(hipFuncSetAttribute((const void*)k_tree_pipe<KP<50, BBH_CRIT_DIAMETER>, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pipe_layout(50).total));
+            BB_HIP(hipFuncSetAttribute((const void*)k_tree_pipe<KP<254, BBH_CRIT_DIAMETER>, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pipe_layout(254).total));
             fast_attr_done = true;
         }
     }
@@ -2467,7 +2469,13 @@ int run_insert_multi(std::vector<Job>& jobs, hipStream_t s) {
                     if (e != hipSuccess) { rc = bb::fail(BBH_ERR_HIP, "H2D: %s", hipGetErrorString(e)); break; }
                 }
                 log_kernel = "pipe";
-                hipLaunchKernelGGL(pk->fn, grid, block, pk->lds, s, dptr);
+                static const bool pipe_phases = getenv("BBHIP_PIPE_PHASES") != nullptr;
+                if (pipe_phases && pk->crit == BBH_CRIT_DIAMETER && pk->bf == 50)
+                    hipLaunchKernelGGL((k_tree_pipe<KP<50, BBH_CRIT_DIAMETER>, true>), grid, block, pk->lds, s, dptr);
+                else if (pipe_phases && pk->crit == BBH_CRIT_DIAMETER)
+                    hipLaunchKernelGGL((k_tree_pipe<KP<254, BBH_CRIT_DIAMETER>, true>), grid, block, pk->lds, s, dptr);
+                else
+                    hipLaunchKernelGGL(pk->fn, grid, block, pk->lds, s, dptr);
             } else if (fk != nullptr && prof_phases && f_packed) {
                 log_kernel = "fast+phases";
                 if (all50) hipLaunchKernelGGL((k_tree_fast<KF50P, true>), grid, block, fk->lds, s, dptr);
@@ -3016,6 +3024,14 @@ extern "C" int bbh_tree_stats(bbh_tree* t, uint64_t* out8) {
     if (!t || !out8) return bb::fail(BBH_ERR_INVALID, "null argument");
     for (int i = 0; i < 7; ++i) out8[i] = t->h.stats[i];
     out8[7] = t->h.ctr[C_IDS];
+    if (getenv("BBHIP_PIPE_PHASES")) {
+        static const char* nm[16] = {"router:setup", "router:wait", "router:compare", "router:commit", "router:drain", "leaf:wait", "leaf:fill",
+                                     "leaf:compare", "leaf:cf+dot", "leaf:decide+apply", "all:flush", "all:cold", "#runs", "#cold", "#fills", "#cfloads"};
+        const double n = (double)(t->h.stats[2] + t->h.stats[3]);
+        fprintf(stderr, "[bbhip pipe phases, per insert]");
+        for (int i = 0; i < 16; ++i) fprintf(stderr, " %s=%.*f", nm[i], i < 12 ? 0 : 4, n > 0 ? (double)t->h.phase[i] / n : 0.0);
+        fprintf(stderr, "\n");
+    }
     if (getenv("BBHIP_PHASES")) {
         fprintf(stderr, "[bbhip phases, cycles/insert]");
         const double n = (double)(t->h.stats[2] + t->h.stats[3]);

@@ -12,6 +12,10 @@ static uint64_t g_reuse_hist[12]; /* leaf reuse distance: 1,2,<=4,<=8,...  */
 static uint64_t g_depth_hist[MAXLV];
 static uint64_t g_lvl_from_leaf_flip[8], g_lvl_from_leaf_vis[8], g_lvl_from_leaf_zero[8], g_lvl_from_leaf_n[8];
 static uint64_t g_row0[8], g_samerow_prev[8];
+#define NC 5
+static const int csz[NC] = {2, 4, 8, 16, 32};
+static Sub* cache[NC][32]; static uint64_t g_chit[NC], g_cacc;
+static uint64_t g_same_target_prev; static Sub* prev_target;
 
 /* a tiny map Node* -> last element index that went to this leaf (open addressing) */
 #define HB 22
@@ -90,6 +94,20 @@ int main(int argc, char** argv) {
             *last = (uint64_t)e + 1;
             if (leaf->len == bf) g_fullhit++;
             if (leaf->subs[pr[D]]->n == 1) g_single_target++;
+            else {
+                Sub* T = leaf->subs[pr[D]];
+                g_cacc++;
+                for (int c = 0; c < NC; ++c) {
+                    int hit = -1;
+                    for (int q = 0; q < csz[c]; ++q) if (cache[c][q] == T) hit = q;
+                    if (hit >= 0) g_chit[c]++;
+                    int from = hit >= 0 ? hit : csz[c] - 1;
+                    for (int q = from; q > 0; --q) cache[c][q] = cache[c][q - 1];
+                    cache[c][0] = T;
+                }
+            }
+            if (leaf->subs[pr[D]] == prev_target) g_same_target_prev++;
+            prev_target = leaf->subs[pr[D]];
             for (int l = 0; l <= D; ++l) { prev_path_node[l] = pn[l]; prev_path_row[l] = pr[l]; }
             prev_D = D;
         }
@@ -101,6 +119,7 @@ int main(int argc, char** argv) {
            (unsigned long long)st[2], (unsigned long long)st[3], (unsigned long long)st[4], (unsigned long long)st[5], (unsigned long long)st[6]);
     printf("levels above leaf per element %.3f, of which all-zero %.3f\n", (double)g_levels / N, (double)g_zero_levels / N);
     printf("full-leaf hits %.4f  singleton targets %.4f\n", (double)g_fullhit / N, (double)g_single_target / N);
+    printf("non-singleton targets %.4f; LRU CF cache hit rate:", (double)g_cacc / N); for (int c = 0; c < NC; ++c) printf(" [%d] %.3f", csz[c], (double)g_chit[c] / (g_cacc ? g_cacc : 1)); printf("  same target as prev elem %.4f\n", (double)g_same_target_prev / N);
     printf("leaf depth hist:"); for (int i = 0; i < 12; ++i) printf(" %llu", (unsigned long long)g_depth_hist[i]); printf("\n");
     printf("leaf reuse distance hist (<=1,2,4,8,...,1024,more):"); for (int i = 0; i < 12; ++i) printf(" %.4f", (double)g_reuse_hist[i] / N); printf("\n");
     for (int fl = 1; fl < 8; ++fl) if (g_lvl_from_leaf_vis[fl])
