@@ -3026,7 +3026,7 @@ extern "C" int bbh_tree_stats(bbh_tree* t, uint64_t* out8) {
     out8[7] = t->h.ctr[C_IDS];
     if (getenv("BBHIP_PIPE_PHASES")) {
         static const char* nm[16] = {"router:setup", "router:wait", "router:compare", "router:commit", "router:drain", "leaf:wait", "leaf:fill",
-                                     "leaf:compare", "leaf:cf+dot", "leaf:decide+apply", "all:flush", "all:cold", "#runs", "#cold", "#fills", "#cfloads"};
+                                     "leaf:compare", "leaf:cf+dot", "leaf:decide+apply", "all:flush", "all:cold", "#runs", "#router-stale", "#leaf-pre-hits", "#leaf-stale"};
         const double n = (double)(t->h.stats[2] + t->h.stats[3]);
         fprintf(stderr, "[bbhip pipe phases, per insert]");
         for (int i = 0; i < 16; ++i) fprintf(stderr, " %s=%.*f", nm[i], i < 12 ? 0 : 4, n > 0 ? (double)t->h.phase[i] / n : 0.0);
