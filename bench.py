@@ -116,6 +116,19 @@ WORKLOADS = {
 }
 
 
+def kernel_src_sha() -> str:
+    r"""sha256 over the device sources of libbbhip.so: what a PMC measurement has to match to describe this build
+    (the GPU box has no .git; tools/profile_bench.sh stores the same hash next to its counters)."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in sorted((REPO / "bblean_amd" / "csrc").glob("*")):
+        if f.suffix in (".hip", ".inc", ".h"):
+            h.update(f.name.encode())
+            h.update(f.read_bytes())
+    return h.hexdigest()[:16]
+
+
 def _cpu_model() -> str:
     try:
         for line in open("/proc/cpuinfo"):
@@ -170,6 +183,20 @@ def _cpu_round1(args_):
     return {k: np.asarray(v) for k, v in bufs.items()}, {k: (v.counts, v.flat) for k, v in mols.items()}
 
 
+def _cpu_round2(args_):
+    r"""One batch of the CPU multiround baseline's merge round, in a pool worker."""
+    batch, common = args_
+    import numpy as np
+    from oracle_engine import OracleEngine
+
+    from bblean_amd.bitbirch import _IndexLists
+    from bblean_amd.multiround import _merge_rounds
+
+    tree = _merge_rounds([[(t, _IndexLists(*i)) for t, i in batch]], engine_factory=OracleEngine, **common)[0]
+    bufs, mols = tree._bf_tables(tree._leaf_order(True))
+    return {k: np.asarray(v) for k, v in bufs.items()}, {k: (v.counts, v.flat) for k, v in mols.items()}
+
+
 def cpu_multiround_baseline(files: list[Path], bf: int, thr: float, bin_size: int = 10) -> dict:
     r"""the N-process multiround CPU baseline - round 1 in a process pool of
     min(shards, host cores) workers (the reference's `mp.Pool`, multiround.py:419-422), merge rounds in one
@@ -194,27 +221,29 @@ def cpu_multiround_baseline(files: list[Path], bf: int, thr: float, bin_size: in
         for name in bufs:
             entries.append((f"label-{lab}-{name.replace('8', '08')}", name, bufs[name], _IndexLists(*mols[name])))
     entries.sort(key=lambda e: e[0])
-    common = dict(branching_factor=bf, tolerance=0.05, engine_factory=OracleEngine, device=0, threshold=thr,
-                  criterion="tolerance-diameter")
+    common = dict(branching_factor=bf, tolerance=0.05, device=0, threshold=thr, criterion="tolerance-diameter")
     batches = [sorted(b, key=lambda e: int(e[1][4:]), reverse=True) for b in batched(entries, bin_size)]
-    trees = _merge_rounds([[(t, i) for _, _, t, i in b] for b in batches], **common)
+    # the reference runs the batches of a merge round in a process pool as well (multiround.py:443-455)
+    nproc2 = max(1, min(len(batches), os.cpu_count() or 1))
+    with mp.get_context("fork").Pool(nproc2) as pool:
+        r2 = pool.map(_cpu_round2, [([(t, (i.counts, i.flat)) for _, _, t, i in b], common) for b in batches])
     z = len(str(len(batches)))
     entries = []
-    for b, tree in enumerate(trees):
-        bufs, mols = tree._bf_tables(tree._leaf_order(True))
+    for b, (bufs, mols) in enumerate(r2):
         for name in bufs:
-            entries.append((f"label-{str(b).zfill(z)}-{name.replace('8', '08')}", name, bufs[name], mols[name]))
+            entries.append((f"label-{str(b).zfill(z)}-{name.replace('8', '08')}", name, bufs[name], _IndexLists(*mols[name])))
     entries.sort(key=lambda e: e[0])
     t2 = time.perf_counter()
-    final = _merge_rounds([[(t, i) for _, _, t, i in entries]], **common)[0]
+    final = _merge_rounds([[(t, i) for _, _, t, i in entries]], engine_factory=OracleEngine, **common)[0]
     k = len(final._leaves()["ids"])
     t3 = time.perf_counter()
     rows = infos[-1][3]
     return {"value": rows / (t3 - t0), "unit": "fingerprints/s", "kind": "port", "cores": nproc, "nproc": os.cpu_count(),
             "cpu_model": _cpu_model(), "rows": rows, "files": len(files), "clusters": k,
             "rounds_s": {"round-1": round(t1 - t0, 3), "round-2": round(t2 - t1, 3), "round-3": round(t3 - t2, 3)},
-            "sample": f"{rows} rows of the same workload in {len(files)} shard files; round 1 in {nproc} processes, "
-                      "merge rounds sequential (one process per tree, as in the reference)"}
+            "sample": f"{rows} rows of the same workload in {len(files)} shard files; round 1 in {nproc} processes, the "
+                      f"merge round's {len(batches)} batches in {nproc2} processes (the reference's pools, multiround.py:419-455), "
+                      "the final merge in one"}
 
 
 def _free_port() -> int:
@@ -245,6 +274,7 @@ def parse() -> argparse.Namespace:
     ap.add_argument("--k1-rows", type=int, default=8_000_000)
     ap.add_argument("--shards", type=int, default=512)
     ap.add_argument("--multiround-files", type=int, default=64, help="0 skips the file-based multiround run")
+    ap.add_argument("--no-extras", action="store_true", help="skip the bf 254 and one-rank distributed sub-records")
     ap.add_argument("--distributed", action="store_true",
                     help="time the one-rank-per-GPU multiround path even at N=1 (what N>1 always times)")
     return ap.parse_args()
@@ -334,6 +364,21 @@ def multi_gpu(args: argparse.Namespace, world: int) -> None:
                       dtype=torch.int64, device=dev)
     ex_all = [torch.zeros_like(ex) for _ in range(world)]
     dist.all_gather(ex_all, ex)
+    cpu_mr = None
+    if rank == 0 and not args.no_cpu:
+        # the same job on this host's cores: one shard file per rank with this rank's generator seeds, the oracle engine
+        # under the file-based multiround host code (round 1 and the merge round's batches in process pools)
+        import tempfile
+
+        import numpy as np
+
+        with tempfile.TemporaryDirectory() as d:
+            names = []
+            for r in range(world):
+                f = Path(d) / f"fps.{r:05d}.npy"
+                np.save(f, gen(n, 1000 + r, dev).cpu().numpy())
+                names.append(f)
+            cpu_mr = cpu_multiround_baseline(names, args.bf, args.threshold)
     if rank == 0:
         avg_ms = total_ms / max(launches, 1)
         achieved = BYTES_PER_FP * (units / max(launches, 1)) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
@@ -367,8 +412,10 @@ def multi_gpu(args: argparse.Namespace, world: int) -> None:
                                             for i, k in enumerate(names) if k != "round-1"},
             },
             "roofline": {
-                "kernel": "k_tree_fast / k_tree_insert on rank 0 (all launches of the timed steps)",
+                "kernel": "k_tree_pipe / k_tree_fast / k_tree_insert on rank 0 (all launches of the timed steps)",
                 "bound": "hbm",
+                "limiter": "dependency chain of the sequential algorithm, not bandwidth",
+                "traffic_source": None,
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
@@ -379,7 +426,7 @@ def multi_gpu(args: argparse.Namespace, world: int) -> None:
                 "elements_per_launch": units / max(launches, 1),
                 "note": "latency/dependency-bound sequential insertion; 264 algorithmic bytes per inserted element",
             },
-            "cpu_baseline": None,
+            "cpu_baseline": cpu_mr,
         }
         print(json.dumps(out), flush=True)
     dist.barrier()
@@ -435,6 +482,44 @@ def single_gpu(args: argparse.Namespace) -> None:
     e2e = time.perf_counter() - t1
     n_clusters = int(labels.max())
     del t_e2e
+
+    # bf 254 is the default of `bb run` / `bb multiround` (BASELINE configs 3-5): the same rows into one tree at bf 254
+    bf254 = None
+    if args.bf != 254 and not args.no_extras:
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        t254 = BitBirch(branching_factor=254, threshold=args.threshold, merge_criterion="diameter", device=local_rank).fit(fps)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t1
+        bf254 = {"branching_factor": 254, "seconds": dt, "fingerprints_per_s": n / dt, "stats": [int(v) for v in t254._engine.stats()[:7]]}
+        del t254
+
+    # the rank path (what --gpus N times) on this one GPU: 8 shards of n / 8 rows resident in HBM through
+    # run_multiround_distributed with one RCCL rank (round 1, table "exchange" on the device, merge round, final merge, labels)
+    dist_one = None
+    if not args.no_extras:
+        try:
+            import torch.distributed as dist
+
+            from bblean_amd.multiround import run_multiround_distributed
+
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(_free_port()))
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+            per = n // 8
+            parts = [fps[i * per:(i + 1) * per] for i in range(8)]
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            dtree, dtimer = run_multiround_distributed(parts, None, branching_factor=args.bf, threshold=args.threshold,
+                                                       device=local_rank, return_tree=True)
+            dlabels = dtree.get_assignments()
+            dt = time.perf_counter() - t1
+            dist_one = {"shards": 8, "rows": 8 * per, "seconds": dt, "fingerprints_per_s": 8 * per / dt, "rccl_ranks": 1,
+                        "clusters": int(dlabels.max()), "rounds_s": {k: round(float(v), 3) for k, v in dtimer.timings.items()}}
+            del dtree, dlabels
+            dist.destroy_process_group()
+        except Exception as exc:  # the sub-record must not take the headline down with it
+            dist_one = {"error": repr(exc)[:200]}
 
     # K1 (arr-vec Tanimoto): the HBM-bound kernel, on an array larger than the 256 MiB
     # Infinity Cache so that the rate is an HBM rate (the 1 M-row workload itself is 256 MB)
@@ -534,16 +619,21 @@ def single_gpu(args: argparse.Namespace) -> None:
                         "note": "file-compatible multiround with the reference's defaults (full refinement, one merge "
                                 "round in bins of 10, tolerance-diameter merges); files on tmpfs/disk inside the timing"}
             if not args.no_cpu:
-                # bounded: a quarter of the files (same rows per file) so that the default run stays within minutes
-                cpu_mr = cpu_multiround_baseline(names[: max(2, args.multiround_files // 4)], args.bf, args.threshold)
+                # the SAME files as the GPU leg (1 M rows: about 15 s on the host's cores)
+                cpu_mr = cpu_multiround_baseline(names, args.bf, args.threshold)
         del host
 
-    traffic = None
+    # HBM traffic of the tree kernel: NOT measured in this run - PMC counters need rocprofv3 (separate passes,
+    # tools/profile_bench.sh); the committed measurement is only quoted when it was taken on this very kernel source
+    traffic, traffic_source = None, None
     pmc = REPO / "profiles" / "pmc_latest.json"
+    src_sha = kernel_src_sha()
     if pmc.is_file():
         try:
             rec = json.loads(pmc.read_text())
-            if int(rec.get("n_fps", -1)) == n:
+            traffic_source = {"file": "profiles/pmc_latest.json", "kernel_src_sha": rec.get("kernel_src_sha"),
+                              "this_build_src_sha": src_sha, "n_fps": rec.get("n_fps")}
+            if int(rec.get("n_fps", -1)) == n and rec.get("kernel_src_sha") == src_sha:
                 # FETCH_SIZE/WRITE_SIZE are in KB; FETCH_SIZE reads 1/2 on gfx950 (MI355X_MICROARCH.md)
                 traffic = (2.0 * rec["tree_fetch_kb_total"] + rec["tree_write_kb_total"]) * 1024.0 / max(rec["tree_launches"], 1)
         except Exception:
@@ -568,13 +658,15 @@ def single_gpu(args: argparse.Namespace) -> None:
             "clusters": n_clusters,
         },
         "roofline": {
-            "kernel": "k_tree_fast (the tree insertion kernel)",
+            "kernel": "k_tree_pipe (the pipelined tree insertion kernel; k_tree_fast / the complete engine for the stretches it hands over)",
             "bound": "hbm",
+            "limiter": "dependency chain of the sequential algorithm (instruction issue of two specialised waves), not bandwidth",
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic,
+            "traffic_source": traffic_source,
             "launches": k_launches,
             "avg_launch_ms": avg_ms,
             "elements_per_launch": units / k_launches,
@@ -603,6 +695,8 @@ def single_gpu(args: argparse.Namespace) -> None:
             "frac": k2_laneops / k2_peak,
             "queries": nq2, "centroids": nc2, "avg_launch_ms": k2_ms,
         },
+        "bf254": bf254,
+        "distributed_one_rank": dist_one,
         "concurrent_shards": shard_stats,
         "multiround_one_gpu": mr_stats,
         "cpu_multiround_baseline": cpu_mr,

@@ -23,6 +23,16 @@ def _gpu_available() -> bool:
         return False
 
 
+def rccl_world() -> int:
+    r"""Ranks of the RCCL tests: one per visible GPU, at most 8 (1 on the one-GPU box and on CPU, where they are skipped)."""
+    try:
+        import torch
+
+        return max(1, min(torch.cuda.device_count(), 8))
+    except Exception:
+        return 1
+
+
 def pytest_collection_modifyitems(config, items):
     if _gpu_available():
         return

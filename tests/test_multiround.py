@@ -77,8 +77,10 @@ _WORKER = r"""
 import os, sys, pickle
 from pathlib import Path
 sys.path.insert(0, {repo!r}); sys.path.insert(0, {repo!r} + "/tests"); sys.path.insert(0, {repo!r} + "/tests/golden")
-import torch.distributed as dist
+import torch, torch.distributed as dist
 from bblean_amd.multiround import run_multiround_distributed
+if {backend!r} == "nccl":
+    torch.cuda.set_device(int(sys.argv[1]) % max(torch.cuda.device_count(), 1))  # one rank per GPU
 engine = None
 if {use_oracle}:
     from oracle_engine import OracleEngine as engine
@@ -117,22 +119,30 @@ def test_multiround_distributed_gloo_world2(case):
     _check(case, clusters)
 
 
+from conftest import rccl_world
+
+_RCCL_W = rccl_world()
+
+
 @pytest.mark.gpu
-def test_multiround_distributed_rccl_world1_hip():
-    r"""The one-process-per-GPU entry point on the real stack: HIP engine + torch.distributed
-    "nccl" (= RCCL) collectives on device tensors.  One rank only (the GPU box has one device;
-    RCCL refuses two ranks on one GPU) - the world-2 exchange logic is covered by the gloo test."""
+@pytest.mark.parametrize("world", [_RCCL_W], ids=[f"world{_RCCL_W}"])
+def test_multiround_distributed_rccl_hip(world):
+    r"""The one-process-per-GPU entry point on the real stack: HIP engine + torch.distributed "nccl" (= RCCL)
+    point-to-point exchange of device tensors, ONE RANK PER VISIBLE GPU (world 1 on the one-GPU box, where RCCL
+    refuses two ranks on one device - the world-2 exchange logic is then covered by the gloo tests; world N on an
+    N-GPU node, without anyone editing the test)."""
     case = MULTIROUND_CASES[0]
     kwargs = {k: v for k, v in case["kwargs"].items()}
     with tempfile.TemporaryDirectory() as d:
         d = Path(d)
         _write_files(d, case)
         (d / "out").mkdir()
-        src = _WORKER.format(repo=str(REPO), use_oracle=False, backend="nccl", port=_free_port(), world=1, d=str(d), kwargs=kwargs)
+        src = _WORKER.format(repo=str(REPO), use_oracle=False, backend="nccl", port=_free_port(), world=world, d=str(d), kwargs=kwargs)
         (d / "worker.py").write_text(src)
         env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-        p = subprocess.Popen([sys.executable, str(d / "worker.py"), "0"], env=env)
-        assert p.wait(timeout=600) == 0
+        procs = [subprocess.Popen([sys.executable, str(d / "worker.py"), str(r)], env=env) for r in range(world)]
+        for p in procs:
+            assert p.wait(timeout=900) == 0
         clusters = pickle.load(open(d / "clusters_rank0.pkl", "rb"))
     _check(case, clusters)
 

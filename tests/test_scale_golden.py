@@ -51,8 +51,10 @@ _WORKER = r"""
 import os, sys, pickle
 from pathlib import Path
 sys.path.insert(0, {repo!r}); sys.path.insert(0, {repo!r} + "/tests"); sys.path.insert(0, {repo!r} + "/tests/golden")
-import torch.distributed as dist
+import torch, torch.distributed as dist
 from bblean_amd.multiround import run_multiround_distributed
+if {backend!r} == "nccl":
+    torch.cuda.set_device(int(sys.argv[1]) % max(torch.cuda.device_count(), 1))  # one rank per GPU
 engine = None
 if {use_oracle}:
     from oracle_engine import OracleEngine as engine
@@ -102,12 +104,20 @@ def test_configs_4_5_distributed_gloo_world2_oracle(case, tmp_path):
     assert ex[1]["round-3"]["received"] == 0  # the final merge happens on rank 0 only
 
 
+from conftest import rccl_world
+
+_RCCL_W = rccl_world()
+
+
 @pytest.mark.gpu
+@pytest.mark.parametrize("world", [_RCCL_W], ids=[f"world{_RCCL_W}"])
 @pytest.mark.parametrize("case", MULTIROUND_SCALE_CASES[:2], ids=[c["name"] for c in MULTIROUND_SCALE_CASES[:2]])
-def test_configs_4_5_distributed_rccl_world1_hip(case, tmp_path):
-    r"""The same on the real stack: HIP engine, torch.distributed "nccl" (= RCCL), BitFeature tables resident in
-    HBM from the gather kernel to the next round's insertion kernel."""
-    _run_distributed(case, tmp_path, use_oracle=False, backend="nccl", world=1)
+def test_configs_4_5_distributed_rccl_hip(case, world, tmp_path):
+    r"""The same on the real stack: HIP engine, torch.distributed "nccl" (= RCCL), one rank per visible GPU, BitFeature
+    tables resident in HBM from the gather kernel to the next round's insertion kernel."""
+    ex = _run_distributed(case, tmp_path, use_oracle=False, backend="nccl", world=world)
+    if world > 1:
+        assert sum(b["sent"] for per in ex for b in per.values()) > 0
 
 
 @pytest.mark.gpu

@@ -12,13 +12,13 @@ OUT="/tmp/prof_$TAG"
 rm -rf "$OUT"; mkdir -p "$OUT" "$FINAL"
 export TMPDIR=/tmp
 cd /tmp
-CMD="python $ROOT/bench.py --steps 1 --warmup 0 --n-fps $NFPS --no-cpu --shards 0 --multiround-files 0 --k1-rows $K1ROWS"
+CMD="python $ROOT/bench.py --steps 1 --warmup 0 --n-fps $NFPS --no-cpu --shards 0 --multiround-files 0 --no-extras --k1-rows $K1ROWS"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o bench -- $CMD > "$OUT/bench_trace.log" 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o bench -- $CMD > "$OUT/bench_pmc_fetch.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o bench -- $CMD > "$OUT/bench_pmc_write.log" 2>&1
 for f in "$OUT"/*.log; do grep -m1 metric "$f" | cut -c1-200; done
 find "$OUT" -name "*.csv" | head -50
-python - "$OUT" "$NFPS" <<'PY'
+BB_ROOT="$ROOT" python - "$OUT" "$NFPS" <<'PY'
 import csv, sys, glob, collections, os
 out = sys.argv[1]
 rec = {}
@@ -38,12 +38,20 @@ for name in ("pmc_fetch", "pmc_write"):
                 line = f"{k:60s} {c:12s} dispatches={n:6d} total={v:.1f} per_dispatch={v/max(n,1):.1f}"
                 print(line); w.write(line + "\n")
                 if "k_tree" in k:
-                    rec["tree_" + ("fetch" if c == "FETCH_SIZE" else "write") + "_kb_total"] = v
-                    rec["tree_launches"] = n
+                    key = "tree_" + ("fetch" if c == "FETCH_SIZE" else "write")
+                    rec[key + "_kb_total"] = rec.get(key + "_kb_total", 0.0) + v   # all tree kernels (k_tree_pipe, k_tree_fast ...)
+                    rec[key + "_dispatches"] = rec.get(key + "_dispatches", 0) + n
+                    rec["tree_launches"] = rec[key + "_dispatches"]
                 if "k_arr_vec<16, true>" in k:
                     rec["k1_" + ("fetch" if c == "FETCH_SIZE" else "write") + "_kb_per_dispatch"] = v / max(n, 1)
 import json
 rec["n_fps"] = int(sys.argv[2])
+sys.path.insert(0, os.environ.get("BB_ROOT", "."))
+try:
+    import bench
+    rec["kernel_src_sha"] = bench.kernel_src_sha()
+except Exception as exc:
+    rec["kernel_src_sha"] = None
 rec["note"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), raw KB as reported; FETCH_SIZE must be doubled on gfx950 (MI355X_MICROARCH.md)"
 open(os.path.join(out, "pmc_latest.json"), "w").write(json.dumps(rec, indent=1))
 print(rec)
