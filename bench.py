@@ -505,7 +505,16 @@ def single_gpu(args: argparse.Namespace) -> None:
 
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", str(_free_port()))
-            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+            # (RCCL prints its version banner on stdout when the first communicator comes up: keep stdout to the ONE JSON line)
+            sys.stdout.flush()
+            saved_fd = os.dup(1)
+            os.dup2(2, 1)
+            try:
+                dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+                dist.barrier()
+            finally:
+                os.dup2(saved_fd, 1)
+                os.close(saved_fd)
             per = n // 8
             parts = [fps[i * per:(i + 1) * per] for i in range(8)]
             torch.cuda.synchronize()
