@@ -21,6 +21,7 @@ Two front ends over the same round logic:
 from __future__ import annotations
 
 import itertools
+import os
 import math
 import pickle
 import time
@@ -367,17 +368,12 @@ class _Exchange:
             t = torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1))
         return t if t.device == self.tdev else t.to(self.tdev)
 
-    def run(self, mine: list[Entry], bin_size: int | None, owner: tp.Callable[[int], int],
-            z_width: int | None = None) -> tuple[list[tuple[int, list[Entry]]], int]:
-        r"""Returns ([(batch index, entries of that batch in file order) for the batches this rank
-        merges], total number of batches).  `bin_size=None`: one batch with everything."""
+    def _plan(self, mine: list[Entry], bin_size: int | None) -> list[list[tuple]]:
+        r"""Steps 1 and 2: the descriptor all-gather and the batches every rank derives from it.  A plan entry is
+        (key, src rank, src position, label, name, rows, columns, member ids)."""
         import torch
 
-        from bblean_amd._engine import DevTable
-
-        dist, world, rank = self.dist, self.world, self.rank
-        on_dev = self.tdev.type == "cuda"
-        # 1. descriptors
+        dist, world = self.dist, self.world
         cnt = torch.tensor([len(mine)], dtype=torch.int64, device=self.tdev)
         cnts = [torch.zeros(1, dtype=torch.int64, device=self.tdev) for _ in range(world)]
         dist.all_gather(cnts, cnt)
@@ -385,12 +381,14 @@ class _Exchange:
         cap = max(max(counts), 1)
         desc = torch.zeros((cap, 6), dtype=torch.int64)
         for i, (lab, name, table, idx) in enumerate(mine):
+            if not lab.isdigit():
+                raise ValueError(f"table labels must be numeric, got {lab!r}")
             desc[i] = torch.tensor([int(lab), len(lab), _CODE[name], int(table.shape[0]), int(table.shape[1]),
                                     int(idx.flat.size)], dtype=torch.int64)
         desc = desc.to(self.tdev)
         all_desc = [torch.zeros((cap, 6), dtype=torch.int64, device=self.tdev) for _ in range(world)]
         dist.all_gather(all_desc, desc)
-        plan = []  # (key, src rank, src position, label, name, k, cols, n ids)
+        plan = []
         for r in range(world):
             rows = all_desc[r].cpu().numpy()
             for i in range(counts[r]):
@@ -398,8 +396,148 @@ class _Exchange:
                 lab, name = str(lab_i).zfill(lab_w), _NAME[bits]
                 plan.append((_entry_key(lab, name), r, i, lab, name, k, cols, nids))
         plan.sort(key=lambda e: e[0])
-        # 2. batches and their owners
-        chunks = [plan] if bin_size is None else [list(c) for c in batched(plan, bin_size)]
+        return [plan] if bin_size is None else [list(c) for c in batched(plan, bin_size)]
+
+    def run_streaming(self, mine: list[Entry], bin_size: int | None, owner: tp.Callable[[int], int], budget_bytes: int,
+                      widest_first: bool, make_tree: tp.Callable[[], BitBirch]) -> tuple[list[tuple[int, BitBirch]], int]:
+        r"""The exchange and the merge in one, with bounded memory on the merging rank (the reference's final round
+        reads ONE ``(bufs, idxs)`` pair at a time from disk, multiround.py:284-312; holding every table of a batch next
+        to the tree built from them does not fit 288 GB at 100 M rows that hardly merge).  Every batch's tables are cut,
+        in insertion order, into chunks of rows of at most `budget_bytes` and packed into slabs of at most that size;
+        slab s + 1 of every batch is on the wire (one grouped `batch_isend_irecv` per step, the same sequence of steps on
+        all ranks) while slab s is inserted, so the merging rank holds two slabs and its trees, nothing else.  The member
+        lists of a table (8 bytes per molecule) travel with its first chunk.  `widest_first`: the merge rounds' order
+        inside a batch, uint16 tables before uint8 (multiround.py:104-111).  Returns ([(batch, tree) for the batches
+        this rank merges], number of batches); same trees as `run` + `_merge_rounds`, chunk for chunk the same stream."""
+        import torch
+
+        from bblean_amd._engine import DevTable
+
+        dist, rank = self.dist, self.rank
+        batches = self._plan(mine, bin_size)
+        if widest_first:
+            batches = [sorted(b, key=lambda e: _CODE[e[4]], reverse=True) for b in batches]
+        # slabs[b] = [[(plan entry, first row, end row, is first chunk)], ...]
+        slabs: list[list[list[tuple]]] = []
+        for chunk in batches:
+            cur: list[tuple] = []
+            cur_bytes = 0
+            out: list[list[tuple]] = []
+            for ent in chunk:
+                _, _, _, _, name, k, cols, _ = ent
+                row_bytes = cols * np.dtype(name).itemsize
+                per = max(1, budget_bytes // max(row_bytes, 1))
+                a = 0
+                while a < k or (k == 0 and a == 0):
+                    b_ = min(k, a + per)
+                    nb = (b_ - a) * row_bytes
+                    if cur and cur_bytes + nb > budget_bytes:
+                        out.append(cur)
+                        cur, cur_bytes = [], 0
+                    cur.append((ent, a, b_, a == 0))
+                    cur_bytes += nb
+                    a = b_
+                    if k == 0:
+                        break
+            if cur:
+                out.append(cur)
+            slabs.append(out)
+        owned = [b for b in range(len(batches)) if owner(b) == rank]
+        trees = {b: make_tree() for b in owned}
+        members: dict[tuple[int, str], _IndexLists] = {}   # (batch, key) -> the table's member lists, once its first chunk is here
+        offsets: dict[tuple[int, str], NDArray[np.int64]] = {}
+        n_steps = max((len(x) for x in slabs), default=0)
+
+        def post(step: int) -> tuple[list, dict]:
+            ops, got = [], {}
+            for b, sl in enumerate(slabs):
+                if step >= len(sl):
+                    continue
+                dst = owner(b)
+                for pos, (ent, a, b_, first) in enumerate(sl[step]):
+                    key, src, i, lab, name, k, cols, nids = ent
+                    item = np.dtype(name).itemsize
+                    if src == rank and dst == rank:
+                        _, _, table, idx = mine[i]
+                        part = DevTable(table.raw[a:b_], table.width) if hasattr(table, "raw") else table[a:b_]
+                        got[(b, pos)] = (key, name, part, idx if first else None, a, b_)
+                    elif src == rank:
+                        _, _, table, idx = mine[i]
+                        rows = table.raw[a:b_] if hasattr(table, "raw") else np.ascontiguousarray(table[a:b_])
+                        parts = [self._wire(DevTable(rows, table.width) if hasattr(table, "raw") else rows)]
+                        if first:
+                            parts += [self._wire(idx.counts.astype(np.int64)), self._wire(idx.flat.astype(np.int64))]
+                        for t in parts:
+                            if t.numel():
+                                ops.append(dist.P2POp(dist.isend, t, dst))
+                                self.bytes_sent += int(t.numel())
+                        got.setdefault("_keep", []).append(parts)  # (alive until the step's requests are done)
+                    elif dst == rank:
+                        tb = torch.empty((b_ - a, cols * item), dtype=torch.uint8, device=self.tdev)
+                        bufs = [tb]
+                        if first:
+                            bufs += [torch.empty(k * 8, dtype=torch.uint8, device=self.tdev),
+                                     torch.empty(nids * 8, dtype=torch.uint8, device=self.tdev)]
+                        for t in bufs:
+                            if t.numel():
+                                ops.append(dist.P2POp(dist.irecv, t.reshape(-1), src))
+                                self.bytes_received += int(t.numel())
+                        got[(b, pos)] = (key, name, bufs, None, a, b_)
+            reqs = dist.batch_isend_irecv(ops) if ops else []
+            return reqs, got
+
+        def finish(reqs: list, got: dict) -> dict[int, list[tuple[tp.Any, _IndexLists]]]:
+            for req in reqs:
+                req.wait()
+            if reqs and self.tdev.type == "cuda":
+                torch.cuda.synchronize()
+            per_batch: dict[int, list[tuple[int, tuple[tp.Any, _IndexLists]]]] = {}
+            for kpos, val in got.items():
+                if kpos == "_keep":
+                    continue
+                b, pos = kpos
+                key, name, payload, idx_full, a, b_ = val
+                if isinstance(payload, list):  # received
+                    tb = payload[0]
+                    if len(payload) == 3:
+                        idx_full = _IndexLists(payload[1].cpu().numpy().view(np.int64).copy(), payload[2].cpu().numpy().view(np.int64).copy())
+                    if self.table_dev is not None:
+                        part = DevTable(tb if tb.device == self.table_dev else tb.to(self.table_dev), np.dtype(name).itemsize)
+                    else:
+                        part = tb.numpy().view(np.dtype(name)).reshape(b_ - a, -1)
+                else:
+                    part = payload
+                if idx_full is not None:
+                    members[(b, key)] = idx_full
+                    offsets[(b, key)] = np.concatenate(([0], np.cumsum(idx_full.counts)))
+                full, off = members[(b, key)], offsets[(b, key)]
+                sub = _IndexLists(full.counts[a:b_], full.flat[int(off[a]):int(off[b_])])
+                per_batch.setdefault(b, []).append((pos, (part, sub)))
+            return {b: [e for _, e in sorted(v, key=lambda pe: pe[0])] for b, v in per_batch.items()}
+
+        pending = post(0) if n_steps else ([], {})
+        for step in range(n_steps):
+            ready = finish(*pending)
+            pending = post(step + 1) if step + 1 < n_steps else ([], {})  # the next slab travels while this one is inserted
+            live = [b for b in owned if b in ready]
+            if live:
+                fit_buffers_concurrently([trees[b] for b in live], [ready[b] for b in live])
+            del ready
+        for t in trees.values():
+            t.delete_internal_nodes()
+        return [(b, trees[b]) for b in owned], len(batches)
+
+    def run(self, mine: list[Entry], bin_size: int | None, owner: tp.Callable[[int], int],
+            ) -> tuple[list[tuple[int, list[Entry]]], int]:
+        r"""Returns ([(batch index, entries of that batch in file order) for the batches this rank
+        merges], total number of batches).  `bin_size=None`: one batch with everything."""
+        import torch
+
+        from bblean_amd._engine import DevTable
+
+        dist, rank = self.dist, self.rank
+        on_dev = self.tdev.type == "cuda"
+        chunks = self._plan(mine, bin_size)  # 1. descriptors, 2. batches and their owners
         # 3. payloads
         ops, recv_into = [], {}
         mine_out: dict[int, list[tp.Any]] = {}
@@ -439,6 +577,7 @@ class _Exchange:
             else:
                 table = tb.numpy().view(np.dtype(name)).reshape(k, cols)
             mine_out.setdefault(b, []).append((pos, (lab, name, table, _IndexLists(cnt_np, ids_np))))
+            recv_into[(b, pos)] = None  # (the staging tensors of the member lists are not kept next to the tables)
         out = [(b, [e for _, e in sorted(v, key=lambda pe: pe[0])]) for b, v in sorted(mine_out.items())]
         return out, len(chunks)
 
@@ -463,6 +602,7 @@ def run_multiround_distributed(
     max_fps: int | None = None,
     device: int | None = None,
     return_tree: bool = False,
+    recv_budget_mb: float | None = None,
     _engine_factory: tp.Any = None,
 ) -> tuple[tp.Any, _Timer]:
     r"""Multiround (reference multiround.py:333-484) with one rank per GPU (`torch.distributed` must be
@@ -477,12 +617,21 @@ def run_multiround_distributed(
     ranks.  Returns (clusters on rank 0 - or the final tree with `return_tree` - / None elsewhere,
     timings); writes clusters.pkl on rank 0 when `out_dir` is given.  `timer.exchange` holds the bytes
     this rank sent / received per round.
+
+    `recv_budget_mb` (default: the environment variable ``BBHIP_RECV_BUDGET_MB``, unset = unbounded): a merging rank
+    then never holds more than two slabs of that size of the tables it merges - they arrive in insertion order, slab
+    s + 1 on the wire while slab s is inserted (`_Exchange.run_streaming`) - instead of every table of its batches.
+    Same clusters; what makes 100 M rows that hardly merge fit one GPU's 288 GB on the rank of the final merge.
+    (`_engine_factory` is a test hook: the CPU oracle engine.)
     """
     import torch
     import torch.distributed as dist
 
     if final_merge_criterion is None:
         final_merge_criterion = midsection_merge_criterion
+    if recv_budget_mb is None and os.environ.get("BBHIP_RECV_BUDGET_MB"):
+        recv_budget_mb = float(os.environ["BBHIP_RECV_BUDGET_MB"])
+    budget = None if recv_budget_mb is None else max(1, int(recv_budget_mb * (1 << 20)))
     rank, world = dist.get_rank(), dist.get_world_size()
     on_gpu = dist.get_backend() == "nccl"
     dev_index = (torch.cuda.current_device() if device is None else device) if on_gpu else (device or 0)
@@ -516,14 +665,24 @@ def run_multiround_distributed(
         round_idx += 1
         timer.init_timing(f"round-{round_idx}")
         ex = _Exchange(dist, tdev, table_dev)
-        my_batches, n_batches = ex.run(mine, bin_size, lambda b: b % world)
+        if budget is not None:
+            def mk_mid() -> BitBirch:
+                return BitBirch(branching_factor=branching_factor, threshold=threshold + midsection_threshold_change,
+                                merge_criterion=midsection_merge_criterion, tolerance=tolerance, device=dev_index,
+                                _engine_factory=_engine_factory)
+
+            owned, n_batches = ex.run_streaming(mine, bin_size, lambda b: b % world, budget, True, mk_mid)
+            ordered = [(b, None) for b, _ in owned]
+            trees = [t for _, t in owned]
+        else:
+            my_batches, n_batches = ex.run(mine, bin_size, lambda b: b % world)
+            ordered = [(b, sorted(batch, key=lambda e: _CODE[e[1]], reverse=True)) for b, batch in my_batches]  # uint16 first
+            trees = _merge_rounds([[(t, idx) for _, _, t, idx in batch] for _, batch in ordered],
+                                  threshold=threshold + midsection_threshold_change,
+                                  criterion=midsection_merge_criterion, **common)
         timer.exchange[f"round-{round_idx}"] = {"sent": ex.bytes_sent, "received": ex.bytes_received}  # type: ignore[attr-defined]
         z = len(str(n_batches))
         mine = []
-        ordered = [(b, sorted(batch, key=lambda e: _CODE[e[1]], reverse=True)) for b, batch in my_batches]  # uint16 first
-        trees = _merge_rounds([[(t, idx) for _, _, t, idx in batch] for _, batch in ordered],
-                              threshold=threshold + midsection_threshold_change,
-                              criterion=midsection_merge_criterion, **common)
         for (b, _), tree in zip(ordered, trees):
             bufs, mols = tree._bf_tables(tree._leaf_order(True), device=dev_tables)
             for name in bufs:
@@ -534,14 +693,26 @@ def run_multiround_distributed(
     round_idx += 1
     timer.init_timing(f"round-{round_idx}")
     ex = _Exchange(dist, tdev, table_dev)
-    final, _ = ex.run(mine, None, lambda b: 0)
+    tree: tp.Any = None
+    if budget is not None:
+        def mk_final() -> BitBirch:
+            return BitBirch(branching_factor=branching_factor, threshold=threshold + midsection_threshold_change,
+                            merge_criterion=final_merge_criterion, tolerance=tolerance, device=dev_index,
+                            _engine_factory=_engine_factory)
+
+        owned, _ = ex.run_streaming(mine, None, lambda b: 0, budget, False, mk_final)
+        if rank == 0:
+            tree = owned[0][1] if owned else mk_final()
+    else:
+        final, _ = ex.run(mine, None, lambda b: 0)
+        if rank == 0:
+            everything = final[0][1] if final else []
+            tree = _merge_rounds([[(t, idx) for _, _, t, idx in everything]], threshold=threshold + midsection_threshold_change,
+                                 criterion=final_merge_criterion, **common)[0]
     timer.exchange[f"round-{round_idx}"] = {"sent": ex.bytes_sent, "received": ex.bytes_received}  # type: ignore[attr-defined]
     del mine
     result: tp.Any = None
     if rank == 0:
-        everything = final[0][1] if final else []
-        tree = _merge_rounds([[(t, idx) for _, _, t, idx in everything]], threshold=threshold + midsection_threshold_change,
-                             criterion=final_merge_criterion, **common)[0]
         result = tree if return_tree else tree.get_cluster_mol_ids()
         if out_dir is not None:
             _write_outputs(Path(out_dir), tree, save_centroids)

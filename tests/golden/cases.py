@@ -44,6 +44,32 @@ def dense_rdkit_like(n: int, n_features: int, seed: int) -> np.ndarray:
     return out
 
 
+def sparse_ecfp_words(n: int, n_features: int, seed: int) -> np.ndarray:
+    r"""S-ecfp at the size of BASELINE config 3 (10 M rows) in half a minute: the same construction as
+    `sparse_ecfp_like` (n/50 planted prototypes of ~48 bits, about an eighth of a row's bits dropped, ~8 random bits
+    added) built from 64-bit random WORDS - a bit is dropped where three random words agree on 1 (1/8), added where
+    eight (three words and five rotated copies of them) do (~1/256) - instead of one random double per bit (160 GB of them at this size).  Packed uint8."""
+    rng = np.random.default_rng(seed)
+    k = max(n // 50, 1)
+    w = n_features // 64
+    pops = np.clip(np.rint(rng.normal(48, 12, k)), 8, 160)
+    protos = np.empty((k, w), dtype=np.uint64)
+    for lo in range(0, k, 20_000):
+        m = min(20_000, k - lo)
+        bits = rng.random((m, n_features)) < (pops[lo:lo + m] / n_features)[:, None]
+        protos[lo:lo + m] = np.packbits(bits, axis=1).view(np.uint64)
+    out = np.empty((n, n_features // 8), dtype=np.uint8)
+    for lo in range(0, n, 100_000):
+        m = min(100_000, n - lo)
+        which = rng.integers(0, k, m)
+        r = rng.integers(0, np.iinfo(np.uint64).max, size=(6, m, w), dtype=np.uint64, endpoint=True)
+        drop = r[0] & r[1] & r[2]
+        rot = lambda a, c: (a << np.uint64(c)) | (a >> np.uint64(64 - c))  # noqa: E731  (rotated copies stand in for more words)
+        add = r[3] & r[4] & r[5] & rot(r[3], 17) & rot(r[4], 29) & rot(r[5], 7) & rot(r[3], 41) & rot(r[4], 3)
+        out[lo:lo + m] = ((protos[which] & ~drop) | add).view(np.uint8)
+    return out
+
+
 def fake_chunks(n: int, seed0: int, make_fake, n_features: int = 2048) -> np.ndarray:
     r"""S-fake(N, seed): chunk c of 100 000 rows = make_fake_fingerprints(100_000, seed=seed0 + c)
     (the 1 M-row array of BASELINE.md section 2 is fake_chunks(1_000_000, 1000))."""
@@ -61,6 +87,8 @@ def make_input(case: dict, make_fake) -> np.ndarray:
         return fake_chunks(n, case["seed"], make_fake, nf)
     if kind == "sparse":
         return sparse_ecfp_like(n, nf, case["seed"])
+    if kind == "sparse_words":
+        return sparse_ecfp_words(n, nf, case["seed"])
     if kind == "rdkit":
         return dense_rdkit_like(n, nf, case["seed"])
     if kind == "zeros":
@@ -147,6 +175,8 @@ SCALE_CASES = [
     _c("rdkit_100k", 100_000, 50, 0.6, "diameter", seed=2026, kind="rdkit"),
     _c("rdkit_bf254_100k", 100_000, 254, 0.6, "diameter", seed=2027, kind="rdkit"),
     _c("fake_1M", 1_000_000, 50, 0.3, "diameter", seed=1000, kind="fake_chunks", gpu_only=True),
+    # BASELINE config 3 at its own size: 10 M S-ecfp rows, the CLI's default branching factor, `--refine-num 1`
+    _c("ecfp_10M_bf254_refine", 10_000_000, 254, 0.3, "diameter", seed=3003, kind="sparse_words", refine=_REFINE_TD, gpu_only=True),
 ]
 
 # BASELINE configs 4 and 5 at test scale: 8 shard files through multiround with the CLI defaults

@@ -74,11 +74,14 @@ def _free_port() -> int:
         return s.getsockname()[1]
 
 
-def _run_distributed(case: dict, d: Path, *, use_oracle: bool, backend: str, world: int):
+def _run_distributed(case: dict, d: Path, *, use_oracle: bool, backend: str, world: int, recv_budget_mb: float | None = None):
     write_shards(d, case)
     (d / "out").mkdir()
+    kwargs = dict(case["kwargs"])
+    if recv_budget_mb is not None:
+        kwargs["recv_budget_mb"] = recv_budget_mb
     src = _WORKER.format(repo=str(REPO), use_oracle=use_oracle, backend=backend, port=_free_port(), world=world, d=str(d),
-                         kwargs=dict(case["kwargs"]))
+                         kwargs=kwargs)
     (d / "worker.py").write_text(src)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     procs = [subprocess.Popen([sys.executable, str(d / "worker.py"), str(r)], env=env) for r in range(world)]
@@ -127,6 +130,32 @@ def test_configs_4_5_distributed_world2_hip_device_tables(case, tmp_path):
     gloo): tables are gathered into HBM, handed to the exchange as tensors and inserted from HBM by the receiving
     rank - no NumPy table on the way."""
     ex = _run_distributed(case, tmp_path, use_oracle=False, backend="gloo", world=2)
+    assert sum(b["sent"] for per in ex for b in per.values()) > 0
+
+
+# ---- bounded receive: the merging rank takes its tables in slabs (reference multiround.py:284-312 reads one pair at a time) ----
+@pytest.mark.parametrize("case", MULTIROUND_SCALE_CASES[:2], ids=[c["name"] for c in MULTIROUND_SCALE_CASES[:2]])
+def test_configs_4_5_distributed_gloo_world2_oracle_bounded_receive(case, tmp_path):
+    r"""BASELINE configs 4 / 5 at test scale with a receive budget far below one table (a 25 k-row uint8 table is 51 MB):
+    every table crosses the wire and enters the tree in slabs of 3 MB, slab s + 1 travelling while slab s is inserted -
+    the reference's clusters, byte for byte the same outputs as the unbounded exchange."""
+    ex = _run_distributed(case, tmp_path, use_oracle=True, backend="gloo", world=2, recv_budget_mb=3)
+    assert sum(b["sent"] for per in ex for b in per.values()) == sum(b["received"] for per in ex for b in per.values()) > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [_RCCL_W], ids=[f"world{_RCCL_W}"])
+@pytest.mark.parametrize("case", MULTIROUND_SCALE_CASES[:2], ids=[c["name"] for c in MULTIROUND_SCALE_CASES[:2]])
+def test_configs_4_5_distributed_rccl_hip_bounded_receive(case, world, tmp_path):
+    r"""The same on the real stack (HIP engine, RCCL, tables resident in HBM, one rank per visible GPU), budget 3 MB."""
+    _run_distributed(case, tmp_path, use_oracle=False, backend="nccl", world=world, recv_budget_mb=3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", MULTIROUND_SCALE_CASES[:1], ids=[c["name"] for c in MULTIROUND_SCALE_CASES[:1]])
+def test_config_4_distributed_world2_hip_bounded_receive(case, tmp_path):
+    r"""Two ranks with the HIP engine on the one GPU of the box (gloo wire), budget 3 MB: chunks of device tables."""
+    ex = _run_distributed(case, tmp_path, use_oracle=False, backend="gloo", world=2, recv_budget_mb=3)
     assert sum(b["sent"] for per in ex for b in per.values()) > 0
 
 
