@@ -567,7 +567,56 @@ __device__ __forceinline__ Cand node_best(const KCt& k, int& cmp_par, uint32_t n
     if (k.RBc == 16) {
         const u32x4_t xv = vec[l];
         const uint32_t last = rows - 1;
-        for (uint32_t r0 = 0; r0 < rows; r0 += 64) {
+        uint32_t r_start = 0;
+        if constexpr (!ROOT) {
+            // Nodes far larger than the block's 16 rows per pass (branching factors of several hundred: nothing of them is
+            // mirrored in LDS, every level streams from L2): 16 passes = 256 rows requested before the first is consumed,
+            // instead of one memory round trip per 64 rows.
+            if (!fill && rows > 256) {
+                constexpr int NP = 16;
+                for (; r_start + NP * 16 <= rows + NP * 16 - 1 && r_start < rows; r_start += NP * 16) {
+                    u32x4_t d[NP];
+                    uint32_t cd[NP];
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) {
+                        const uint32_t r = r_start + p * 16 + g;
+                        const uint32_t rc = r < last ? r : last;
+                        d[p] = ldg<u32x4_t>(k.cent + (meta + rc) * 256 + l * 16);
+                        cd[p] = ldg<uint32_t>(k.card + meta + rc);
+                    }
+                    if (want_link) {
+#pragma unroll
+                        for (int p = 0; p < NP; ++p) {
+                            const uint32_t r = r_start + p * 16 + g;
+                            if (l == 0 && r < rows) s_link[r] = ldg<uint32_t>(k.link + meta + r);
+                        }
+                    }
+                    if (r_start == 0) {
+                        if (load_hdr) {
+                            len = uni(hraw.x);
+                            leaf = uni(hraw.y);
+                        } else {
+                            len = (uint32_t)known_len;
+                        }
+                    }
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) {
+                        const uint32_t r = r_start + p * 16 + g;
+                        const uint32_t both = row16_sum(popc4v(d[p] & xv) + (l == 0 ? cd[p] << 16 : 0u));
+                        const uint32_t inter = both & 0xFFFFu;
+                        uint32_t un = (both >> 16) + vec_pc - inter;
+                        anyc = anyc || (r < len && (both >> 16) != 0);
+                        if (want_counts && r < len && l == 0) { s_i[r] = inter; s_u[r] = un; }
+                        un = un < 1u ? 1u : un;
+                        const bool take = r < len && cand_better<MINMODE>(inter, un, r, bi, bu, br);
+                        bi = take ? inter : bi;
+                        bu = take ? un : bu;
+                        br = take ? r : br;
+                    }
+                }
+            }
+        }
+        for (uint32_t r0 = r_start; r0 < rows; r0 += 64) {
             // branch-free: row indices are clamped instead of predicated so that all loads of
             // the pass are issued back to back; out-of-range rows are discarded by `r < len`
             u32x4_t d[4];
@@ -2303,32 +2352,38 @@ int configure(bbh_tree* t, int32_t bf, int32_t n_features) {
     h.scratch_cent = nullptr;
     BB_HIP(bb::dev_alloc(&h.scratch_cent, ((size_t)bf + 1) * h.RB));
     {
-        // dynamic LDS above 48 KiB has to be allowed per kernel; the attribute is process-wide, so it is only ever
-        // raised: to the CU's 160 KiB, once (trees of different shapes share the kernels)
-        static bool attr_done = false;
-        if (!attr_done) {
-            const int cap = 160 * 1024;
+        // dynamic LDS above 48 KiB has to be allowed per kernel AND per device (HIP function objects are per device): raised once
+        // per device, to what that device offers (160 KiB on gfx950; trees of different shapes share the kernels)
+        static std::mutex attr_mu;
+        static std::vector<bool> attr_done_dev(64, false);
+        std::lock_guard<std::mutex> lock(attr_mu);
+        const size_t di = (size_t)std::min(std::max(t->device, 0), 63);
+        if (!attr_done_dev[di]) {
+            hipDeviceProp_t prop;
+            BB_HIP(hipGetDeviceProperties(&prop, t->device));
+            // (gfx950: 160 KiB per workgroup; elsewhere - BBHIP_ALLOW_ANY_ARCH - whatever a compute unit has)
+            const bool is950 = std::strncmp(prop.gcnArchName, "gfx950", 6) == 0;
+            const int cap = is950 ? 160 * 1024 : (int)std::min<size_t>(prop.maxSharedMemoryPerMultiProcessor, 160 * 1024);
             BB_HIP(hipFuncSetAttribute((const void*)k_tree_insert<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
             BB_HIP(hipFuncSetAttribute((const void*)k_tree_insert<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
             BB_HIP(hipFuncSetAttribute((const void*)k_tree_insert<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
             BB_HIP(hipFuncSetAttribute((const void*)k_tree_insert_dense<KC>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
             BB_HIP(hipFuncSetAttribute((const void*)k_tree_insert<true, false, KC50>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
-            attr_done = true;
-        }
-    }
-    {
-        // the steady-state kernels use the CU's whole LDS whatever this tree's own layout needs
-        static bool fast_attr_done = false;
-        if (!fast_attr_done) {
-            for (const FastKernel& fk : kFastKernels)
-                BB_HIP(hipFuncSetAttribute((const void*)fk.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fk.lds));
-            BB_HIP(hipFuncSetAttribute((const void*)k_tree_fast<KF50P, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast_layout(50).total));
-            BB_HIP(hipFuncSetAttribute((const void*)k_tree_fast<KF254P, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast_layout(254).total));
-            for (const PipeKernel& pk : kPipeKernels)
-                BB_HIP(hipFuncSetAttribute((const void*)pk.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pk.lds));
-            BB_HIP(hipFuncSetAttribute((const void*)k_tree_pipe<KP<50, BBH_CRIT_DIAMETER>, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pipe_layout(50).total));
-            BB_HIP(hipFuncSetAttribute((const void*)k_tree_pipe<KP<254, BBH_CRIT_DIAMETER>, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pipe_layout(254).total));
-            fast_attr_done = true;
+            // the steady-state / pipelined kernels use the CU's whole LDS whatever this tree's own layout needs
+            if ((uint32_t)cap >= pipe_layout(254).total && (uint32_t)cap >= fast_layout(254).total) {
+                for (const FastKernel& fk : kFastKernels)
+                    BB_HIP(hipFuncSetAttribute((const void*)fk.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fk.lds));
+                BB_HIP(hipFuncSetAttribute((const void*)k_tree_fast<KF50P, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast_layout(50).total));
+                BB_HIP(hipFuncSetAttribute((const void*)k_tree_fast<KF254P, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast_layout(254).total));
+                for (const PipeKernel& pk : kPipeKernels)
+                    BB_HIP(hipFuncSetAttribute((const void*)pk.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pk.lds));
+                BB_HIP(hipFuncSetAttribute((const void*)k_tree_pipe<KP<50, BBH_CRIT_DIAMETER>, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pipe_layout(50).total));
+                BB_HIP(hipFuncSetAttribute((const void*)k_tree_pipe<KP<254, BBH_CRIT_DIAMETER>, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pipe_layout(254).total));
+            } else {
+                return bb::fail(BBH_ERR_NO_DEVICE, "device %d offers %d bytes of LDS per workgroup, the tree kernels need %u", t->device, cap,
+                                pipe_layout(254).total);
+            }
+            attr_done_dev[di] = true;
         }
     }
     return BBH_OK;
