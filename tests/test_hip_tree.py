@@ -206,6 +206,28 @@ def test_hip_tree_full_size_1M_vs_oracle():
     assert (lv_h["cents"] == lv_o["cents"]).all() and (lv_h["n"] == lv_o["n"]).all()
 
 
+@pytest.mark.parametrize("bf", [50, 254])
+def test_hip_pipelined_kernel_tier_promotions_vs_oracle(bf):
+    r"""The pipelined kernel's own corners (bb_tree_pipe.inc): BitFeatures that move up a tier while elements are in flight
+    (runs of 400 duplicates cross 255 members: uint8 -> uint16 cluster features, decided and applied by the leaf engine), full
+    leaves, in-place splits and the tolerance criterion of the merge rounds, on sparse rows - the upper tree levels keep
+    all-zero centroids, the shape the pipelined kernel takes (a 70 000-fold duplicate would dominate every ancestor's
+    majority vote and hand the tree to k_tree_fast; the uint32 tier is covered by the "tiers" case above).  Element by
+    element the oracle's leaf ids and counters."""
+    protos = sparse_ecfp_like(60, 2048, 91)
+    singles = sparse_ecfp_like(90_000, 2048, 92)
+    # (runs of 400 copies of one row between stretches of distinct rows: shuffled, BitBIRCH scatters the copies over many
+    # leaves and no cluster reaches 256 members)
+    fps = np.concatenate([np.concatenate([singles[k * 1500:(k + 1) * 1500], np.repeat(protos[k:k + 1], 400, axis=0)]) for k in range(60)])
+    kw = dict(branching_factor=bf, threshold=0.65, merge_criterion="tolerance-diameter", tolerance=0.05)
+    hip = BitBirch(**kw).fit(fps)
+    ora = BitBirch(_engine_factory=OracleEngine, **kw).fit(fps)
+    assert (hip._log_leaf[-1] == ora._log_leaf[-1]).all()
+    assert hip._engine.stats()[:7].tolist() == ora._engine.stats()[:7].tolist()
+    _same(hip, ora)
+    assert int(np.bincount(hip.get_assignments()).max()) >= 256  # (the uint16 tier was reached)
+
+
 @pytest.mark.parametrize("bf", [254, 1000])
 def test_hip_tree_1M_large_branching_factors_vs_oracle(bf):
     r"""The CLI default (bf 254) and the branching factor the reference recommends for 100-200 M molecules (bf 1000,
