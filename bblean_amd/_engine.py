@@ -32,6 +32,14 @@ def _launch_stream(x: object) -> int | None:
     return int(torch.cuda.current_stream(x.device).cuda_stream)  # type: ignore[attr-defined]
 
 
+def _one_stream(have: "int | None", new: "int | None") -> "int | None":
+    r"""The many-tree entry points make ONE launch on ONE stream: device inputs produced on different streams (or
+    devices) would only be ordered behind one of their producers."""
+    if have is not None and new is not None and have != new:
+        raise RuntimeError("device inputs of one multi-tree launch must share one device and stream")
+    return new if new is not None else have
+
+
 class DevTable:
     r"""A BitFeature buffer table ``[k, n_features + 1]`` of `width`-byte unsigned integers that lives in
     HBM (multiround's round-* tables, reference multiround.py:132-143, without the trip through host
@@ -171,7 +179,7 @@ class HipEngine:
                     rows = rows.contiguous()
                 n, nb, st = int(rows.shape[0]), int(rows.shape[1]), int(rows.stride(0))
                 keep.append(rows)
-                stream = _launch_stream(rows)
+                stream = _one_stream(stream, _launch_stream(rows))
             else:
                 arr = np.ascontiguousarray(rows, dtype=np.uint8)
                 n, nb = arr.shape
@@ -206,7 +214,7 @@ class HipEngine:
                 ks.append(bufs.shape[0])
                 widths.append(bufs.width)
                 ptrs.append(int(raw.data_ptr()) if bufs.shape[0] else None)
-                stream = _launch_stream(raw)
+                stream = _one_stream(stream, _launch_stream(raw))
             else:
                 b = np.ascontiguousarray(bufs)
                 if b.ndim != 2 or b.shape[1] != eng.n_features + 1:

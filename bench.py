@@ -494,42 +494,6 @@ def single_gpu(args: argparse.Namespace) -> None:
         bf254 = {"branching_factor": 254, "seconds": dt, "fingerprints_per_s": n / dt, "stats": [int(v) for v in t254._engine.stats()[:7]]}
         del t254
 
-    # the rank path (what --gpus N times) on this one GPU: 8 shards of n / 8 rows resident in HBM through
-    # run_multiround_distributed with one RCCL rank (round 1, table "exchange" on the device, merge round, final merge, labels)
-    dist_one = None
-    if not args.no_extras:
-        try:
-            import torch.distributed as dist
-
-            from bblean_amd.multiround import run_multiround_distributed
-
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", str(_free_port()))
-            # (RCCL prints its version banner on stdout when the first communicator comes up: keep stdout to the ONE JSON line)
-            sys.stdout.flush()
-            saved_fd = os.dup(1)
-            os.dup2(2, 1)
-            try:
-                dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
-                dist.barrier()
-            finally:
-                os.dup2(saved_fd, 1)
-                os.close(saved_fd)
-            per = n // 8
-            parts = [fps[i * per:(i + 1) * per] for i in range(8)]
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            dtree, dtimer = run_multiround_distributed(parts, None, branching_factor=args.bf, threshold=args.threshold,
-                                                       device=local_rank, return_tree=True)
-            dlabels = dtree.get_assignments()
-            dt = time.perf_counter() - t1
-            dist_one = {"shards": 8, "rows": 8 * per, "seconds": dt, "fingerprints_per_s": 8 * per / dt, "rccl_ranks": 1,
-                        "clusters": int(dlabels.max()), "rounds_s": {k: round(float(v), 3) for k, v in dtimer.timings.items()}}
-            del dtree, dlabels
-            dist.destroy_process_group()
-        except Exception as exc:  # the sub-record must not take the headline down with it
-            dist_one = {"error": repr(exc)[:200]}
-
     # K1 (arr-vec Tanimoto): the HBM-bound kernel, on an array larger than the 256 MiB
     # Infinity Cache so that the rate is an HBM rate (the 1 M-row workload itself is 256 MB)
     from bblean_amd.similarity import _jt_sim_arr_vec_packed
@@ -631,6 +595,43 @@ def single_gpu(args: argparse.Namespace) -> None:
                 # the SAME files as the GPU leg (1 M rows: about 15 s on the host's cores)
                 cpu_mr = cpu_multiround_baseline(names, args.bf, args.threshold)
         del host
+
+    # (last: a live RCCL communicator slows the many-tree launch measured above by 2x)
+    # the rank path (what --gpus N times) on this one GPU: 8 shards of n / 8 rows resident in HBM through
+    # run_multiround_distributed with one RCCL rank (round 1, table "exchange" on the device, merge round, final merge, labels)
+    dist_one = None
+    if not args.no_extras:
+        try:
+            import torch.distributed as dist
+
+            from bblean_amd.multiround import run_multiround_distributed
+
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(_free_port()))
+            # (RCCL prints its version banner on stdout when the first communicator comes up: keep stdout to the ONE JSON line)
+            sys.stdout.flush()
+            saved_fd = os.dup(1)
+            os.dup2(2, 1)
+            try:
+                dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+                dist.barrier()
+            finally:
+                os.dup2(saved_fd, 1)
+                os.close(saved_fd)
+            per = n // 8
+            parts = [fps[i * per:(i + 1) * per] for i in range(8)]
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            dtree, dtimer = run_multiround_distributed(parts, None, branching_factor=args.bf, threshold=args.threshold,
+                                                       device=local_rank, return_tree=True)
+            dlabels = dtree.get_assignments()
+            dt = time.perf_counter() - t1
+            dist_one = {"shards": 8, "rows": 8 * per, "seconds": dt, "fingerprints_per_s": 8 * per / dt, "rccl_ranks": 1,
+                        "clusters": int(dlabels.max()), "rounds_s": {k: round(float(v), 3) for k, v in dtimer.timings.items()}}
+            del dtree, dlabels
+            dist.destroy_process_group()
+        except Exception as exc:  # the sub-record must not take the headline down with it
+            dist_one = {"error": repr(exc)[:200]}
 
     # HBM traffic of the tree kernel: NOT measured in this run - PMC counters need rocprofv3 (separate passes,
     # tools/profile_bench.sh); the committed measurement is only quoted when it was taken on this very kernel source
