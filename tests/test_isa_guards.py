@@ -40,3 +40,15 @@ def test_fast_kernels_use_no_scratch_memory(tmp_path):
         # and no call inside the steady-state loop: the only calls are the two cold functions of tree_fast_body
         calls = len(re.findall(r"s_swappc_b64", body))
         assert calls <= 2, (name, calls)
+    # the pipelined kernel (bb_tree_pipe.inc): four specialised waves whose loop-carried state lives in registers and LDS -
+    # nothing of it may end up in private memory either, and its only calls are the two cold functions between runs
+    pipes = re.findall(r"^(_ZN\S*k_tree_pipe\S*):", text, re.M)
+    assert len(pipes) >= 4, pipes  # bf 50 / 254 x diameter / tolerance-diameter (+ the phase-timer builds)
+    for name in pipes:
+        start = text.index(name + ":")
+        body = text[start:text.index(".Lfunc_end", start)]
+        scratch = [ln.strip() for ln in body.splitlines() if ln.strip().startswith(("scratch_", "buffer_load", "buffer_store"))]
+        assert not scratch, (name, scratch[:5])
+        m = re.search(r"\.set " + re.escape(name) + r"\.private_seg_size, (\d+)\+max\(", text)
+        assert m is not None and int(m.group(1)) == 0, (name, m.group(0) if m else None)
+        assert len(re.findall(r"s_swappc_b64", body)) <= 2, name
