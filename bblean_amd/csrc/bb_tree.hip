@@ -3085,6 +3085,11 @@ extern "C" int bbh_tree_stats(bbh_tree* t, uint64_t* out8) {
         const double n = (double)(t->h.stats[2] + t->h.stats[3]);
         fprintf(stderr, "[bbhip pipe phases, per insert]");
         for (int i = 0; i < 16; ++i) fprintf(stderr, " %s=%.*f", nm[i], i < 12 ? 0 : 4, n > 0 ? (double)t->h.phase[i] / n : 0.0);
+        static const char* kd[3] = {"pre-compared, best row folded", "own", "pre-compared, every row checked"};
+        fprintf(stderr, "\n[bbhip pipe leaf compares]");
+        for (int i = 0; i < 3; ++i)
+            fprintf(stderr, " %s: %.3f/insert x %.0f cycles", kd[i], n > 0 ? (double)t->h.sphase[2 * i + 1] / n : 0.0,
+                    t->h.sphase[2 * i + 1] ? (double)t->h.sphase[2 * i] / (double)t->h.sphase[2 * i + 1] : 0.0);
         fprintf(stderr, "\n");
     }
     if (getenv("BBHIP_PHASES")) {
