@@ -339,11 +339,24 @@ __device__ __forceinline__ void block_sum_fused(const KCt& k, int& red_slot, boo
 }
 
 // ---- cluster-feature access: 8 consecutive features -----------------------------------
+// Tier 3 ("lazy"): a leaf BitFeature of ONE packed fingerprint that nothing has been merged into yet.  Its linear sum
+// is its centroid (one fingerprint is its own majority vote, bitbirch.py:423-435), which its node holds anyway: its uint8
+// slot is reserved but not written.  The first merge writes the sum of the two members there and the BitFeature
+// becomes tier 0 with the same slot.  Readers pass the BitFeature's centroid row (`crow`).
+constexpr uint32_t TIER_LAZY = 3u;
+__device__ __forceinline__ void byte_to_cols(uint32_t byte, uint32_t v[8]) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = (byte >> (7 - q)) & 1u;
+}
+__device__ __forceinline__ uint32_t slot_after_merge_tier(uint32_t old_tier) { return old_tier == TIER_LAZY ? 0u : old_tier; }
+
 template <class KCt>
-__device__ __forceinline__ void cf_load8(const KCt& k, uint32_t slotw, int b, uint32_t v[8]) {
+__device__ __forceinline__ void cf_load8(const KCt& k, uint32_t slotw, int b, uint32_t v[8], const uint8_t* crow = nullptr) {
     const uint32_t tier = slotw >> 30;
     const size_t idx = (size_t)(slotw & 0x3FFFFFFFu) * (size_t)k.F + (size_t)b * 8;
-    if (tier == 0) {
+    if (tier == TIER_LAZY) {
+        byte_to_cols(ldg<uint8_t>(crow + b), v);
+    } else if (tier == 0) {
         const u32x2_t q = ldg<u32x2_t>(k.cf8 + idx);
         v[0] = q.x & 0xFF; v[1] = (q.x >> 8) & 0xFF; v[2] = (q.x >> 16) & 0xFF; v[3] = q.x >> 24;
         v[4] = q.y & 0xFF; v[5] = (q.y >> 8) & 0xFF; v[6] = (q.y >> 16) & 0xFF; v[7] = q.y >> 24;
@@ -364,8 +377,14 @@ __device__ __forceinline__ void cf_load8(const KCt& k, uint32_t slotw, int b, ui
 // pointed at the same line otherwise.  cf8 rows are 8-byte aligned and over-read by 8 bytes
 // (the pools carry 64 bytes of slack; amdhsa runs with unaligned access enabled).
 template <class KCt>
-__device__ __forceinline__ void cf_load_raw(const KCt& k, uint32_t slotw, int b, u32x4_t (&raw)[2]) {
+__device__ __forceinline__ void cf_load_raw(const KCt& k, uint32_t slotw, int b, u32x4_t (&raw)[2], const uint8_t* crow = nullptr) {
     const uint32_t tier = slotw >> 30;
+    if (tier == TIER_LAZY) {  // (wave-uniform) byte b of the BitFeature's centroid row
+        raw[0] = (u32x4_t)(0);
+        raw[1] = (u32x4_t)(0);
+        raw[0].x = ldg<uint8_t>(crow + b);
+        return;
+    }
     // mask arithmetic, not ?: - the compiler turns a three-way pointer select into a table in scratch
     const u64 m0 = 0ull - (u64)(tier == 0), m1 = 0ull - (u64)(tier == 1), m2 = 0ull - (u64)(tier >= 2);
     const uint8_t* base = (const uint8_t*)(((u64)(uintptr_t)k.cf8 & m0) | ((u64)(uintptr_t)k.cf16 & m1) | ((u64)(uintptr_t)k.cf32 & m2));
@@ -375,7 +394,9 @@ __device__ __forceinline__ void cf_load_raw(const KCt& k, uint32_t slotw, int b,
 }
 __device__ __forceinline__ void cf_unpack_raw(uint32_t tier, const u32x4_t (&raw)[2], uint32_t v[8]) {
     const u32x4_t q = raw[0];
-    if (tier == 0) {
+    if (tier == TIER_LAZY) {
+        byte_to_cols(q.x & 0xFFu, v);
+    } else if (tier == 0) {
         v[0] = q.x & 0xFF; v[1] = (q.x >> 8) & 0xFF; v[2] = (q.x >> 16) & 0xFF; v[3] = q.x >> 24;
         v[4] = q.y & 0xFF; v[5] = (q.y >> 8) & 0xFF; v[6] = (q.y >> 16) & 0xFF; v[7] = q.y >> 24;
     } else if (tier == 1) {
@@ -874,12 +895,12 @@ __device__ __forceinline__ void node_put_row(const KCt& k, uint32_t nd, uint32_t
 
 // ---- radius complement terms (similarity.py:192-202) on CF(slot) [+ element] -----------
 template <class KCt>
-__device__ __forceinline__ void radius_terms(const KCt& k, const Elem& el, int& red_slot, uint32_t slotw, bool add_elem,
+__device__ __forceinline__ void radius_terms(const KCt& k, const Elem& el, int& red_slot, uint32_t slotw, const uint8_t* crow, bool add_elem,
                                              u64 n, u64& sc, u64& sq) {
     u64 acc[2] = {0, 0};
     for (int b = threadIdx.x; b < k.nb; b += TB) {
         uint32_t v[8], e[8];
-        cf_load8(k, slotw, b, v);
+        cf_load8(k, slotw, b, v, crow);
         if (add_elem) {
             elem_cols(k, el, b, e);
 #pragma unroll
@@ -913,7 +934,7 @@ __device__ __forceinline__ double tol_lookup(const KCt& k, u64 old_n) {
 // merge_accept_fn(threshold, new_ls, new_n, old_ls, nom_ls, old_n, nom_n) of _merges.py,
 // on exact moments.  Uniform across the block.
 template <class KCt>
-__device__ __forceinline__ bool merge_accept(const KCt& k, const Elem& el, int& red_slot, uint32_t slotT, u64 nT, u64 s1T,
+__device__ __forceinline__ bool merge_accept(const KCt& k, const Elem& el, int& red_slot, uint32_t slotT, const uint8_t* crowT, u64 nT, u64 s1T,
                                              u64 s2T, u64 new_n, u64 s1n, u64 s2n) {
     const double thr = k.thr;
     const int crit = KCt::crit_fixed >= 0 ? KCt::crit_fixed : k.crit;
@@ -936,16 +957,16 @@ __device__ __forceinline__ bool merge_accept(const KCt& k, const Elem& el, int& 
         }
         case BBH_CRIT_RADIUS: {
             u64 sc, sq;
-            radius_terms(k, el, red_slot, slotT, true, new_n, sc, sq);
+            radius_terms(k, el, red_slot, slotT, crowT, true, new_n, sc, sq);
             return radius_compl(s1n, s2n, sc, sq, new_n) >= thr;
         }
         case BBH_CRIT_TOL_RADIUS: {
             u64 sc, sq;
-            radius_terms(k, el, red_slot, slotT, true, new_n, sc, sq);
+            radius_terms(k, el, red_slot, slotT, crowT, true, new_n, sc, sq);
             const double new_rc = radius_compl(s1n, s2n, sc, sq, new_n);
             if (new_rc < thr) return false;
             if (nT == 1) return true;
-            radius_terms(k, el, red_slot, slotT, false, nT, sc, sq);
+            radius_terms(k, el, red_slot, slotT, crowT, false, nT, sc, sq);
             const double old_rc = radius_compl(s1T, s2T, sc, sq, nT);
             return new_rc >= old_rc - tol_lookup(k, nT);
         }
@@ -1075,6 +1096,12 @@ __device__ __forceinline__ void split_node(const KCt& k, const Elem& el, int& re
     LA u32x4_t* mrm = lds<u32x4_t>(k.L, k.o.mrm);
     LA u32x4_t* vec = lds<u32x4_t>(k.L, k.o.vec);
     LA uint32_t* lst = lds<uint32_t>(k.L, k.o.i1);  // CF slots of the smaller half (after step 5)
+    LA uint32_t* lrow = lds<uint32_t>(k.L, k.o.u1); // and their rows (a lazy BitFeature's cluster features are its centroid row)
+    // byte b of row r's centroid as it was before the rows were distributed (step 7b): the LDS mirror or the staged copy
+    auto row_byte = [&](uint32_t r, int b) -> uint32_t {
+        if (lm) return *(LA uint8_t*)(k.L + k.o.rc_cent + (mrow0 + r) * k.RBS + (uint32_t)b);
+        return ldg<uint8_t>(k.scratch + (size_t)r * (size_t)k.RB + (size_t)b);
+    };
     // 0. row metadata (and, if needed, the centroid rows) to LDS; zero the comparison vector padding
     for (uint32_t r = tid; r < m; r += TB) {
         const uint32_t cd = ldg<uint32_t>(k.card + meta + r);
@@ -1168,7 +1195,7 @@ __device__ __forceinline__ void split_node(const KCt& k, const Elem& el, int& re
             const uint32_t r = r0 + tid;
             if (r < m) {
                 const uint32_t d = dst[r];
-                if (((d & 0x80000000u) != 0) == small1) lst[d & 0x7FFFFFFFu] = mrm[2 * r].z;  // RowMeta.slot
+                if (((d & 0x80000000u) != 0) == small1) { lst[d & 0x7FFFFFFFu] = mrm[2 * r].z; lrow[d & 0x7FFFFFFFu] = r; }  // RowMeta.slot
             }
         }
         if (tid == 0) {
@@ -1262,25 +1289,51 @@ __device__ __forceinline__ void split_node(const KCt& k, const Elem& el, int& re
             cf32_load8(k, trk_slot, b, tot);
             elem_cols(k, el, b, x8);
             for (uint32_t r0 = 0; r0 < ns; r0 += SPLIT_MLP) {  // this many member CFs in flight
-                uint32_t sw[SPLIT_MLP], tiers = 0;
+                uint32_t sw[SPLIT_MLP], rw[SPLIT_MLP], tiers_and = 0xFFFFFFFFu;
+                bool wide = false;
 #pragma unroll
                 for (int u = 0; u < SPLIT_MLP; ++u) {
                     sw[u] = uni(lst[r0 + u < ns ? r0 + u : ns - 1]);
-                    tiers |= sw[u];
+                    rw[u] = uni(lrow[r0 + u < ns ? r0 + u : ns - 1]);
+                    wide = wide || (sw[u] >> 30) == 1u || (sw[u] >> 30) == 2u;
+                    tiers_and &= sw[u];
                 }
-                if ((tiers >> 30) == 0) {
-                    // uint8 CFs only (the usual leaf): 8 bytes per row and thread, summed as four
-                    // pairs of 16-bit lanes (16 rows x 255 cannot overflow them)
+                if ((tiers_and >> 30) == TIER_LAZY) {
+                    // lazy BitFeatures only (a leaf of single fingerprints): the bits of their centroid bytes, four to a
+                    // dword by one 24-bit multiply (bit i of a nibble -> byte i), summed in byte lanes (16 rows at most)
+                    uint32_t lo = 0, hi = 0;
+#pragma unroll
+                    for (int u = 0; u < SPLIT_MLP; ++u) {
+                        if (r0 + u < ns) {
+                            const uint32_t xb = row_byte(rw[u], b);
+                            lo += __umul24(xb & 15u, 0x204081u) & 0x01010101u;
+                            hi += __umul24(xb >> 4, 0x204081u) & 0x01010101u;
+                        }
+                    }
+                    // feature q of the byte is bit 7 - q
+                    sm[7] += lo & 0xFFu; sm[6] += (lo >> 8) & 0xFFu; sm[5] += (lo >> 16) & 0xFFu; sm[4] += lo >> 24;
+                    sm[3] += hi & 0xFFu; sm[2] += (hi >> 8) & 0xFFu; sm[1] += (hi >> 16) & 0xFFu; sm[0] += hi >> 24;
+                } else if (!wide) {
+                    // uint8 CFs (the usual leaf): 8 bytes per row and thread, summed as four pairs of 16-bit lanes
+                    // (16 rows x 255 cannot overflow them).  The requests are branch-free - a lazy BitFeature's reserved
+                    // slot is read and ignored - and its centroid byte takes the loaded pair's place, spread to the
+                    // same layout (feature q of the byte is bit 7 - q: the nibbles' spread bytes reversed).
                     u32x2_t q[SPLIT_MLP];
 #pragma unroll
                     for (int u = 0; u < SPLIT_MLP; ++u)
-                        q[u] = ldg<u32x2_t>(k.cf8 + (size_t)sw[u] * (size_t)k.F + (size_t)b * 8);
+                        q[u] = ldg<u32x2_t>(k.cf8 + (size_t)(sw[u] & 0x3FFFFFFFu) * (size_t)k.F + (size_t)b * 8);
                     uint32_t lx = 0, hx = 0, ly = 0, hy = 0;
 #pragma unroll
                     for (int u = 0; u < SPLIT_MLP; ++u) {
                         if (r0 + u < ns) {
-                            lx += q[u].x & 0x00FF00FFu; hx += (q[u].x >> 8) & 0x00FF00FFu;
-                            ly += q[u].y & 0x00FF00FFu; hy += (q[u].y >> 8) & 0x00FF00FFu;
+                            u32x2_t qq = q[u];
+                            if ((sw[u] >> 30) == TIER_LAZY) {
+                                const uint32_t xb = row_byte(rw[u], b);
+                                qq.x = __builtin_bswap32(__umul24(xb >> 4, 0x204081u) & 0x01010101u);
+                                qq.y = __builtin_bswap32(__umul24(xb & 15u, 0x204081u) & 0x01010101u);
+                            }
+                            lx += qq.x & 0x00FF00FFu; hx += (qq.x >> 8) & 0x00FF00FFu;
+                            ly += qq.y & 0x00FF00FFu; hy += (qq.y >> 8) & 0x00FF00FFu;
                         }
                     }
                     sm[0] += lx & 0xFFFFu; sm[1] += hx & 0xFFFFu; sm[2] += lx >> 16; sm[3] += hx >> 16;
@@ -1290,7 +1343,10 @@ __device__ __forceinline__ void split_node(const KCt& k, const Elem& el, int& re
                     for (int u0 = 0; u0 < SPLIT_MLP; u0 += SPLIT_MLP_WIDE) {
                         u32x4_t raw[SPLIT_MLP_WIDE][2];
 #pragma unroll
-                        for (int u = 0; u < SPLIT_MLP_WIDE; ++u) cf_load_raw(k, sw[u0 + u], b, raw[u]);
+                        for (int u = 0; u < SPLIT_MLP_WIDE; ++u) {
+                            if ((sw[u0 + u] >> 30) == TIER_LAZY) { raw[u][0] = (u32x4_t)(0); raw[u][1] = (u32x4_t)(0); raw[u][0].x = row_byte(rw[u0 + u], b); }
+                            else cf_load_raw(k, sw[u0 + u], b, raw[u]);
+                        }
 #pragma unroll
                         for (int u = 0; u < SPLIT_MLP_WIDE; ++u) {
                             if (r0 + u0 + u < ns) {
@@ -1315,8 +1371,10 @@ __device__ __forceinline__ void split_node(const KCt& k, const Elem& el, int& re
                 uint32_t sw[SPLIT_MLP_WIDE];
 #pragma unroll
                 for (int u = 0; u < SPLIT_MLP_WIDE; ++u) {
-                    sw[u] = uni(mrm[2 * (r0 + u < m ? r0 + u : m - 1)].z);  // RowMeta.slot
-                    cf_load_raw(k, sw[u], b, raw[u]);
+                    const uint32_t ru = r0 + u < m ? r0 + u : m - 1;
+                    sw[u] = uni(mrm[2 * ru].z);  // RowMeta.slot
+                    if ((sw[u] >> 30) == TIER_LAZY) { raw[u][0] = (u32x4_t)(0); raw[u][1] = (u32x4_t)(0); raw[u][0].x = row_byte(ru, b); }
+                    else cf_load_raw(k, sw[u], b, raw[u]);
                 }
 #pragma unroll
                 for (int u = 0; u < SPLIT_MLP_WIDE; ++u) {
@@ -1545,18 +1603,21 @@ __device__ __forceinline__ void tree_insert_body(unsigned char* smem_raw, TreeDe
         if (root_len == 0) {
             // ---- very first element of an empty tree: row 0 of the root leaf -------------
             const uint32_t tier = tier_for(el.nS);
+            const bool lazy = !bufmode && el.nS == 1;  // a packed fingerprint: its cluster features are its centroid (TIER_LAZY)
             const uint32_t s = alloc_n<SUB>(k, cI, gctr + C_IDS, 1, 14);
-            const uint32_t slotw = (tier << 30) | (tier == 0 ? alloc_n<SUB>(k, c8, gctr + C_N8, 1, 15)
+            const uint32_t slotw = ((lazy ? TIER_LAZY : tier) << 30) | (tier == 0 ? alloc_n<SUB>(k, c8, gctr + C_N8, 1, 15)
                                                  : (tier == 1 ? alloc_n<SUB>(k, c16, gctr + C_N16, 1, 15)
                                                               : alloc_n<SUB>(k, c32, gctr + C_N32, 1, 15)));
             if (tid == 0) {
                 stg<uint32_t>(k.hdr + root, 1u);
                 stats[3]++;
             }
-            for (int b = tid; b < nb; b += TB) {
-                uint32_t v[8];
-                elem_cols(k, el, b, v);
-                cf_store8(k, slotw, b, v);
+            if (!lazy) {
+                for (int b = tid; b < nb; b += TB) {
+                    uint32_t v[8];
+                    elem_cols(k, el, b, v);
+                    cf_store8(k, slotw, b, v);
+                }
             }
             node_put_row(k, root, 0, k.o.x, el.pcx, slotw, s, el.nS, slotw, el.s1S, el.s2S);
             out_id = s;
@@ -1656,8 +1717,9 @@ __device__ __forceinline__ void tree_insert_body(unsigned char* smem_raw, TreeDe
             const int DT = D < MAXFAST ? D : MAXFAST;  // ancestors handled in the fused pass
             u32x4_t rawL[2] = {(u32x4_t)(0), (u32x4_t)(0)};
             uint32_t vT[MAXFAST][8];
+            const uint8_t* const crowT = k.cent + ((size_t)leafnode * k.rows + jl) * (size_t)k.RB;  // (a lazy BitFeature's cluster features)
             if (act) {
-                cf_load_raw(k, slotT, b0, rawL);
+                cf_load_raw(k, slotT, b0, rawL, crowT);
 #pragma unroll
                 for (int q = 0; q < MAXFAST; ++q)
                     if (q < DT) cf32_load8(k, tslot[q], b0, vT[q]);
@@ -1708,7 +1770,7 @@ __device__ __forceinline__ void tree_insert_body(unsigned char* smem_raw, TreeDe
             } else {
                 for (int b = tid; b < nb; b += TB) {
                     uint32_t v[8], x8[8];
-                    cf_load8(k, slotT, b, v);
+                    cf_load8(k, slotT, b, v, crowT);
                     elem_cols(k, el, b, x8);
 #pragma unroll
                     for (int q = 0; q < 8; ++q) dot += (u64)v[q] * x8[q];
@@ -1719,13 +1781,13 @@ __device__ __forceinline__ void tree_insert_body(unsigned char* smem_raw, TreeDe
             PHASE(3);
             const u64 s1n = s1T + el.s1S;
             const u64 s2n = s2T + 2ull * dot + el.s2S;
-            const bool accept = merge_accept(k, el, red_slot, slotT, nT, s1T, s2T, new_n, s1n, s2n);
+            const bool accept = merge_accept(k, el, red_slot, slotT, crowT, nT, s1T, s2T, new_n, s1n, s2n);
             const size_t leafm = (size_t)leafnode * k.rows;
             if (accept) {
                 // replace_n_samples_and_linear_sum (bitbirch.py:476-484)
-                const uint32_t old_tier = slotT >> 30;
+                const uint32_t old_tier = slot_after_merge_tier(slotT >> 30);  // (a lazy BitFeature's reserved slot is a uint8 one)
                 const uint32_t new_tier = tier_for(new_n) > old_tier ? tier_for(new_n) : old_tier;
-                uint32_t slotN = slotT;
+                uint32_t slotN = (old_tier << 30) | (slotT & 0x3FFFFFFFu);
                 if (new_tier != old_tier) {
                     slotN = (new_tier << 30) | (new_tier == 1 ? alloc_n<SUB>(k, c16, gctr + C_N16, 1, 15)
                                                               : alloc_n<SUB>(k, c32, gctr + C_N32, 1, 15));
@@ -1744,7 +1806,7 @@ __device__ __forceinline__ void tree_insert_body(unsigned char* smem_raw, TreeDe
                     u64 cc[1] = {0};
                     for (int b = tid; b < nb; b += TB) {
                         uint32_t v[8], x8[8];
-                        cf_load8(k, slotT, b, v);
+                        cf_load8(k, slotT, b, v, crowT);
                         elem_cols(k, el, b, x8);
 #pragma unroll
                         for (int q = 0; q < 8; ++q) v[q] += x8[q];
@@ -1779,15 +1841,17 @@ __device__ __forceinline__ void tree_insert_body(unsigned char* smem_raw, TreeDe
             } else {
                 // append_subcluster (bitbirch.py:284-287): new leaf BitFeature
                 const uint32_t tier = tier_for(el.nS);
+                const bool lazy = !bufmode && el.nS == 1;  // (TIER_LAZY: nothing to write)
                 const uint32_t s = alloc_n<SUB>(k, cI, gctr + C_IDS, 1, 14);
-                const uint32_t slotw = (tier << 30) | (tier == 0 ? alloc_n<SUB>(k, c8, gctr + C_N8, 1, 15)
+                const uint32_t slotw = ((lazy ? TIER_LAZY : tier) << 30) | (tier == 0 ? alloc_n<SUB>(k, c8, gctr + C_N8, 1, 15)
                                                      : (tier == 1 ? alloc_n<SUB>(k, c16, gctr + C_N16, 1, 15)
                                                                   : alloc_n<SUB>(k, c32, gctr + C_N32, 1, 15)));
                 if (tid == 0) {
                     stg<uint32_t>(k.hdr + leafnode, leaflen + 1);
                     stats[3]++;
                 }
-                if (fast) {
+                if (lazy) {
+                } else if (fast) {
                     if (act) cf_store8(k, slotw, b0, xs);
                 } else {
                     for (int b = tid; b < nb; b += TB) {
@@ -2207,6 +2271,7 @@ __global__ __launch_bounds__(256) void k_gather_leaves(TreeDev* Tp, const uint32
         for (int j = threadIdx.x; j < t.F + (ls_only ? 0 : 1); j += blockDim.x) {
             unsigned long long v;
             if (j == t.F) v = n;
+            else if (tier == TIER_LAZY) v = (t.node_cent[((size_t)nd * rows + r) * (size_t)t.RB + (size_t)(j >> 3)] >> (7 - (j & 7))) & 1u;
             else v = tier == 0 ? t.cf8[base + j] : (tier == 1 ? t.cf16[base + j] : t.cf32[base + j]);
             const size_t o = (size_t)i * cols + j;
             switch (width) {

