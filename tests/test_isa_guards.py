@@ -45,6 +45,8 @@ def test_fast_kernels_use_no_scratch_memory(tmp_path):
     pipes = re.findall(r"^(_ZN\S*k_tree_pipe\S*):", text, re.M)
     assert len(pipes) >= 4, pipes  # bf 50 / 254 x diameter / tolerance-diameter (+ the phase-timer builds)
     for name in pipes:
+        if "Lb1EEE" in name:  # PROF = true (BBHIP_PIPE_PHASES): per-kind timers indexed at run time live in memory
+            continue
         start = text.index(name + ":")
         body = text[start:text.index(".Lfunc_end", start)]
         scratch = [ln.strip() for ln in body.splitlines() if ln.strip().startswith(("scratch_", "buffer_load", "buffer_store"))]
