@@ -339,16 +339,16 @@ __device__ __forceinline__ void block_sum_fused(const KCt& k, int& red_slot, boo
 }
 
 // ---- cluster-feature access: 8 consecutive features -----------------------------------
-// Tier 3 ("lazy"): a leaf BitFeature of ONE packed fingerprint that nothing has been merged into yet.  Its linear sum
-// is its centroid (one fingerprint is its own majority vote, bitbirch.py:423-435), which its node holds anyway: its uint8
-// slot is reserved but not written.  The first merge writes the sum of the two members there and the BitFeature
-// becomes tier 0 with the same slot.  Readers pass the BitFeature's centroid row (`crow`).
+// A leaf BitFeature of ONE fingerprint (n_samples == 1) has its linear sum in its centroid row (one fingerprint is its own
+// majority vote, bitbirch.py:423-435), which its node holds anyway: its uint8 slot is reserved when it is appended but a
+// packed fingerprint's is not written, and no reader looks at it.  The first merge writes the sum of the two members
+// there.  Readers are handed an EFFECTIVE slot word with tier TIER_LAZY (never stored) and the centroid row (`crow`).
 constexpr uint32_t TIER_LAZY = 3u;
+__device__ __forceinline__ uint32_t slot_effective(uint32_t slotw, u64 n) { return n == 1 ? ((TIER_LAZY << 30) | (slotw & 0x3FFFFFFFu)) : slotw; }
 __device__ __forceinline__ void byte_to_cols(uint32_t byte, uint32_t v[8]) {
 #pragma unroll
     for (int q = 0; q < 8; ++q) v[q] = (byte >> (7 - q)) & 1u;
 }
-__device__ __forceinline__ uint32_t slot_after_merge_tier(uint32_t old_tier) { return old_tier == TIER_LAZY ? 0u : old_tier; }
 
 template <class KCt>
 __device__ __forceinline__ void cf_load8(const KCt& k, uint32_t slotw, int b, uint32_t v[8], const uint8_t* crow = nullptr) {
@@ -1096,7 +1096,7 @@ __device__ __forceinline__ void split_node(const KCt& k, const Elem& el, int& re
     LA u32x4_t* mrm = lds<u32x4_t>(k.L, k.o.mrm);
     LA u32x4_t* vec = lds<u32x4_t>(k.L, k.o.vec);
     LA uint32_t* lst = lds<uint32_t>(k.L, k.o.i1);  // CF slots of the smaller half (after step 5)
-    LA uint32_t* lrow = lds<uint32_t>(k.L, k.o.u1); // and their rows (a lazy BitFeature's cluster features are its centroid row)
+    LA uint32_t* lrow = lds<uint32_t>(k.L, k.o.u1); // and their rows (a BitFeature of one member has its cluster features in its centroid row)
     // byte b of row r's centroid as it was before the rows were distributed (step 7b): the LDS mirror or the staged copy
     auto row_byte = [&](uint32_t r, int b) -> uint32_t {
         if (lm) return *(LA uint8_t*)(k.L + k.o.rc_cent + (mrow0 + r) * k.RBS + (uint32_t)b);
@@ -1195,7 +1195,7 @@ __device__ __forceinline__ void split_node(const KCt& k, const Elem& el, int& re
             const uint32_t r = r0 + tid;
             if (r < m) {
                 const uint32_t d = dst[r];
-                if (((d & 0x80000000u) != 0) == small1) { lst[d & 0x7FFFFFFFu] = mrm[2 * r].z; lrow[d & 0x7FFFFFFFu] = r; }  // RowMeta.slot
+                if (((d & 0x80000000u) != 0) == small1) { lst[d & 0x7FFFFFFFu] = slot_effective(mrm[2 * r].z, mrm[2 * r].y); lrow[d & 0x7FFFFFFFu] = r; }  // RowMeta.slot (.n == 1: the centroid row)
             }
         }
         if (tid == 0) {
@@ -1299,7 +1299,7 @@ __device__ __forceinline__ void split_node(const KCt& k, const Elem& el, int& re
                     tiers_and &= sw[u];
                 }
                 if ((tiers_and >> 30) == TIER_LAZY) {
-                    // lazy BitFeatures only (a leaf of single fingerprints): the bits of their centroid bytes, four to a
+                    // BitFeatures of one member only (a leaf of single fingerprints): the bits of their centroid bytes, four to a
                     // dword by one 24-bit multiply (bit i of a nibble -> byte i), summed in byte lanes (16 rows at most)
                     uint32_t lo = 0, hi = 0;
 #pragma unroll
@@ -1315,8 +1315,8 @@ __device__ __forceinline__ void split_node(const KCt& k, const Elem& el, int& re
                     sm[3] += hi & 0xFFu; sm[2] += (hi >> 8) & 0xFFu; sm[1] += (hi >> 16) & 0xFFu; sm[0] += hi >> 24;
                 } else if (!wide) {
                     // uint8 CFs (the usual leaf): 8 bytes per row and thread, summed as four pairs of 16-bit lanes
-                    // (16 rows x 255 cannot overflow them).  The requests are branch-free - a lazy BitFeature's reserved
-                    // slot is read and ignored - and its centroid byte takes the loaded pair's place, spread to the
+                    // (16 rows x 255 cannot overflow them).  The requests are branch-free - the reserved slot of a BitFeature of one
+                    // member is read and ignored - and its centroid byte takes the loaded pair's place, spread to the
                     // same layout (feature q of the byte is bit 7 - q: the nibbles' spread bytes reversed).
                     u32x2_t q[SPLIT_MLP];
 #pragma unroll
@@ -1372,7 +1372,7 @@ __device__ __forceinline__ void split_node(const KCt& k, const Elem& el, int& re
 #pragma unroll
                 for (int u = 0; u < SPLIT_MLP_WIDE; ++u) {
                     const uint32_t ru = r0 + u < m ? r0 + u : m - 1;
-                    sw[u] = uni(mrm[2 * ru].z);  // RowMeta.slot
+                    sw[u] = uni(slot_effective(mrm[2 * ru].z, mrm[2 * ru].y));  // RowMeta.slot (.n == 1: the centroid row)
                     if ((sw[u] >> 30) == TIER_LAZY) { raw[u][0] = (u32x4_t)(0); raw[u][1] = (u32x4_t)(0); raw[u][0].x = row_byte(ru, b); }
                     else cf_load_raw(k, sw[u], b, raw[u]);
                 }
@@ -1603,9 +1603,9 @@ __device__ __forceinline__ void tree_insert_body(unsigned char* smem_raw, TreeDe
         if (root_len == 0) {
             // ---- very first element of an empty tree: row 0 of the root leaf -------------
             const uint32_t tier = tier_for(el.nS);
-            const bool lazy = !bufmode && el.nS == 1;  // a packed fingerprint: its cluster features are its centroid (TIER_LAZY)
+            const bool lazy = !bufmode && el.nS == 1;  // a packed fingerprint: its cluster features are its centroid, nothing to write
             const uint32_t s = alloc_n<SUB>(k, cI, gctr + C_IDS, 1, 14);
-            const uint32_t slotw = ((lazy ? TIER_LAZY : tier) << 30) | (tier == 0 ? alloc_n<SUB>(k, c8, gctr + C_N8, 1, 15)
+            const uint32_t slotw = (tier << 30) | (tier == 0 ? alloc_n<SUB>(k, c8, gctr + C_N8, 1, 15)
                                                  : (tier == 1 ? alloc_n<SUB>(k, c16, gctr + C_N16, 1, 15)
                                                               : alloc_n<SUB>(k, c32, gctr + C_N32, 1, 15)));
             if (tid == 0) {
@@ -1718,8 +1718,12 @@ __device__ __forceinline__ void tree_insert_body(unsigned char* smem_raw, TreeDe
             u32x4_t rawL[2] = {(u32x4_t)(0), (u32x4_t)(0)};
             uint32_t vT[MAXFAST][8];
             const uint8_t* const crowT = k.cent + ((size_t)leafnode * k.rows + jl) * (size_t)k.RB;  // (a lazy BitFeature's cluster features)
+            uint32_t cbyteT = 0;
             if (act) {
-                cf_load_raw(k, slotT, b0, rawL, crowT);
+                // (whether the BitFeature has one member is not known yet: both its slot - reserved, possibly never
+                // written - and this thread's byte of its centroid are requested)
+                cf_load_raw(k, slotT, b0, rawL);
+                cbyteT = ldg<uint8_t>(crowT + b0);
 #pragma unroll
                 for (int q = 0; q < MAXFAST; ++q)
                     if (q < DT) cf32_load8(k, tslot[q], b0, vT[q]);
@@ -1730,6 +1734,8 @@ __device__ __forceinline__ void tree_insert_body(unsigned char* smem_raw, TreeDe
             const u64 s2T = ((u64)uni(rm1.w) << 32) | uni(rm1.z);
             const u64 new_n = nT + el.nS;
             if (new_n > 0xFFFFFFFFull) { stop = STOP_RANGE; break; }
+            const uint32_t slotE = slot_effective(slotT, nT);  // (one member: the centroid row is the linear sum)
+            if (nT == 1) { rawL[0] = (u32x4_t)(0); rawL[0].x = cbyteT; }
             // ---- one fused pass: leaf dot product, speculative merged CF + centroid, and
             //      every ancestor's CF += element with its new centroid; one reduction ----
             u64 dot = 0;
@@ -1743,7 +1749,7 @@ __device__ __forceinline__ void tree_insert_body(unsigned char* smem_raw, TreeDe
             if (fast) {
                 if (act) {
                     elem_cols(k, el, b0, xs);
-                    cf_unpack_raw(slotT >> 30, rawL, vL);
+                    cf_unpack_raw(slotE >> 30, rawL, vL);
                     if (wide_dot) {
 #pragma unroll
                         for (int q = 0; q < 8; ++q) dot += (u64)vL[q] * xs[q];
@@ -1770,7 +1776,7 @@ __device__ __forceinline__ void tree_insert_body(unsigned char* smem_raw, TreeDe
             } else {
                 for (int b = tid; b < nb; b += TB) {
                     uint32_t v[8], x8[8];
-                    cf_load8(k, slotT, b, v, crowT);
+                    cf_load8(k, slotE, b, v, crowT);
                     elem_cols(k, el, b, x8);
 #pragma unroll
                     for (int q = 0; q < 8; ++q) dot += (u64)v[q] * x8[q];
@@ -1781,13 +1787,13 @@ __device__ __forceinline__ void tree_insert_body(unsigned char* smem_raw, TreeDe
             PHASE(3);
             const u64 s1n = s1T + el.s1S;
             const u64 s2n = s2T + 2ull * dot + el.s2S;
-            const bool accept = merge_accept(k, el, red_slot, slotT, crowT, nT, s1T, s2T, new_n, s1n, s2n);
+            const bool accept = merge_accept(k, el, red_slot, slotE, crowT, nT, s1T, s2T, new_n, s1n, s2n);
             const size_t leafm = (size_t)leafnode * k.rows;
             if (accept) {
                 // replace_n_samples_and_linear_sum (bitbirch.py:476-484)
-                const uint32_t old_tier = slot_after_merge_tier(slotT >> 30);  // (a lazy BitFeature's reserved slot is a uint8 one)
+                const uint32_t old_tier = slotT >> 30;
                 const uint32_t new_tier = tier_for(new_n) > old_tier ? tier_for(new_n) : old_tier;
-                uint32_t slotN = (old_tier << 30) | (slotT & 0x3FFFFFFFu);
+                uint32_t slotN = slotT;
                 if (new_tier != old_tier) {
                     slotN = (new_tier << 30) | (new_tier == 1 ? alloc_n<SUB>(k, c16, gctr + C_N16, 1, 15)
                                                               : alloc_n<SUB>(k, c32, gctr + C_N32, 1, 15));
@@ -1806,7 +1812,7 @@ __device__ __forceinline__ void tree_insert_body(unsigned char* smem_raw, TreeDe
                     u64 cc[1] = {0};
                     for (int b = tid; b < nb; b += TB) {
                         uint32_t v[8], x8[8];
-                        cf_load8(k, slotT, b, v, crowT);
+                        cf_load8(k, slotE, b, v, crowT);
                         elem_cols(k, el, b, x8);
 #pragma unroll
                         for (int q = 0; q < 8; ++q) v[q] += x8[q];
@@ -1841,9 +1847,9 @@ __device__ __forceinline__ void tree_insert_body(unsigned char* smem_raw, TreeDe
             } else {
                 // append_subcluster (bitbirch.py:284-287): new leaf BitFeature
                 const uint32_t tier = tier_for(el.nS);
-                const bool lazy = !bufmode && el.nS == 1;  // (TIER_LAZY: nothing to write)
+                const bool lazy = !bufmode && el.nS == 1;  // (its cluster features are its centroid: nothing to write)
                 const uint32_t s = alloc_n<SUB>(k, cI, gctr + C_IDS, 1, 14);
-                const uint32_t slotw = ((lazy ? TIER_LAZY : tier) << 30) | (tier == 0 ? alloc_n<SUB>(k, c8, gctr + C_N8, 1, 15)
+                const uint32_t slotw = (tier << 30) | (tier == 0 ? alloc_n<SUB>(k, c8, gctr + C_N8, 1, 15)
                                                      : (tier == 1 ? alloc_n<SUB>(k, c16, gctr + C_N16, 1, 15)
                                                                   : alloc_n<SUB>(k, c32, gctr + C_N32, 1, 15)));
                 if (tid == 0) {
@@ -2271,7 +2277,7 @@ __global__ __launch_bounds__(256) void k_gather_leaves(TreeDev* Tp, const uint32
         for (int j = threadIdx.x; j < t.F + (ls_only ? 0 : 1); j += blockDim.x) {
             unsigned long long v;
             if (j == t.F) v = n;
-            else if (tier == TIER_LAZY) v = (t.node_cent[((size_t)nd * rows + r) * (size_t)t.RB + (size_t)(j >> 3)] >> (7 - (j & 7))) & 1u;
+            else if (n == 1) v = (t.node_cent[((size_t)nd * rows + r) * (size_t)t.RB + (size_t)(j >> 3)] >> (7 - (j & 7))) & 1u;
             else v = tier == 0 ? t.cf8[base + j] : (tier == 1 ? t.cf16[base + j] : t.cf32[base + j]);
             const size_t o = (size_t)i * cols + j;
             switch (width) {
