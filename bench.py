@@ -280,6 +280,13 @@ def parse() -> argparse.Namespace:
     return ap.parse_args()
 
 
+_JSON_FD = 1
+
+
+def _emit(out: dict) -> None:
+    os.write(_JSON_FD, (json.dumps(out) + "\n").encode())
+
+
 def main() -> None:
     args = parse()
     env_world = os.environ.get("WORLD_SIZE")
@@ -289,6 +296,13 @@ def main() -> None:
                "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(Path(__file__).resolve())] + sys.argv[1:]
         env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         sys.exit(subprocess.run(cmd, env=env).returncode)
+    # stdout carries ONE JSON line: everything else any library prints there (RCCL's version banner, through the C library's
+    # buffer, flushed at exit) goes to stderr - file descriptor 1 is pointed at stderr for the rest of the process and the
+    # line is written to the saved descriptor
+    global _JSON_FD
+    sys.stdout.flush()
+    _JSON_FD = os.dup(1)
+    os.dup2(2, 1)
     world = int(env_world or "1")
     if world != args.gpus:
         sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
@@ -428,7 +442,7 @@ def multi_gpu(args: argparse.Namespace, world: int) -> None:
             },
             "cpu_baseline": cpu_mr,
         }
-        print(json.dumps(out), flush=True)
+        _emit(out)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -616,6 +630,11 @@ def single_gpu(args: argparse.Namespace) -> None:
                 dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
                 dist.barrier()
             finally:
+                try:  # (the banner sits in the C library's stdout buffer - fully buffered when stdout is a file - until flushed)
+                    import ctypes
+                    ctypes.CDLL(None).fflush(None)
+                except Exception:
+                    pass
                 os.dup2(saved_fd, 1)
                 os.close(saved_fd)
             per = n // 8
@@ -716,7 +735,7 @@ def single_gpu(args: argparse.Namespace) -> None:
         out["cpu_baseline"] = cpu_baseline(fps[:sample].cpu().numpy(), args.bf, args.threshold)
     else:
         out["cpu_baseline"] = None
-    print(json.dumps(out), flush=True)
+    _emit(out)
 
 
 if __name__ == "__main__":

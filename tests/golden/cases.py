@@ -177,8 +177,8 @@ SCALE_CASES = [
     _c("fake_1M", 1_000_000, 50, 0.3, "diameter", seed=1000, kind="fake_chunks", gpu_only=True),
     # BASELINE config 3 (10 M S-ecfp rows, the CLI's default branching factor) as far as the reference runs in this
     # container's 62 GB: its fit of 10 M rows ran out of memory (stopped at a 58 GB address-space limit, twice), and so did
-    # `--refine-num 1` at that size (old tree + every BitFeature buffer + new tree).  Pinned instead: the fit of the first
-    # 5 M rows of the same generator (reference: 1072 s, 31 GB) and fit + refinement of 3 M rows (565 s).  The 10 M instance
+    # `--refine-num 1` at that size (old tree + every BitFeature buffer + new tree).  Pinned instead: the fit of
+    # 5 M rows of the same generator (reference: 1072 s, 31 GB) and fit + refinement of 3 M rows of the same generator (565 s).  The 10 M instance
     # itself runs in tools/config3.py and profiles/r03/config3_10M_bf254.log (HIP only: timings and tree statistics).
     _c("ecfp_5M_bf254", 5_000_000, 254, 0.3, "diameter", seed=3003, kind="sparse_words", gpu_only=True),
     _c("ecfp_3M_bf254_refine", 3_000_000, 254, 0.3, "diameter", seed=3003, kind="sparse_words", refine=_REFINE_TD, gpu_only=True),
