@@ -228,6 +228,33 @@ def test_hip_pipelined_kernel_tier_promotions_vs_oracle(bf):
     assert int(np.bincount(hip.get_assignments()).max()) >= 256  # (the uint16 tier was reached)
 
 
+@pytest.mark.parametrize("bf", [50, 254])
+def test_hip_pipelined_kernel_drifting_centroids_vs_oracle(bf):
+    r"""Merges that move centroids while elements are in flight, on the tree shape whose leaf-parent is all-zero (sparse
+    rows): short runs of NOISY copies of a prototype between stretches of distinct rows.  Consecutive elements go to the same
+    leaf and the same row, every merge takes a majority vote that can raise or lower the row's similarity to the next
+    element - the leaf engine's short cuts (tagged pre-compares; at bf 254 the helper's first-argmax with the changed rows
+    folded in, including the case "the best row changed and its key went down") have to reproduce np.argmax on the
+    current rows every time.  Element by element the oracle's leaf ids and counters."""
+    rng = np.random.default_rng(931)
+    n_protos, copies, between = 2000, 12, 20
+    protos = np.unpackbits(sparse_ecfp_like(n_protos, 2048, 93), axis=1).astype(bool)
+    singles = sparse_ecfp_like(n_protos * between, 2048, 94)
+    # (few copies per prototype: no feature reaches half of a leaf's rows, the leaf-parent's centroids stay all-zero)
+    keep = rng.random((n_protos, copies, 2048)) > 0.22
+    add = rng.random((n_protos, copies, 2048)) < 0.003
+    noisy = np.packbits((protos[:, None, :] & keep) | add, axis=2)
+    fps = np.concatenate([np.concatenate([singles[k * between:(k + 1) * between], noisy[k]]) for k in range(n_protos)])
+    kw = dict(branching_factor=bf, threshold=0.45, merge_criterion="diameter")
+    hip = BitBirch(**kw).fit(fps)
+    ora = BitBirch(_engine_factory=OracleEngine, **kw).fit(fps)
+    assert (hip._log_leaf[-1] == ora._log_leaf[-1]).all()
+    assert hip._engine.stats()[:7].tolist() == ora._engine.stats()[:7].tolist()
+    _same(hip, ora)
+    st = hip._engine.stats()
+    assert int(st[2]) > 5000  # (the noisy copies do merge)
+
+
 @pytest.mark.parametrize("bf", [254, 1000])
 def test_hip_tree_1M_large_branching_factors_vs_oracle(bf):
     r"""The CLI default (bf 254) and the branching factor the reference recommends for 100-200 M molecules (bf 1000,
