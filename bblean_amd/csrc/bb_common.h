@@ -168,7 +168,8 @@ constexpr int WAVE = 64;
 // DPP row rotate right by N within each 16-lane row (ctrl 0x120 + N); every lane valid.
 template <int N>
 __device__ __forceinline__ uint32_t row_ror(uint32_t v) {
-    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x120 + N, 0xF, 0xF, false);
+    // (`old` = 0, the add's identity: the compiler folds the move into ONE v_add_u32_dpp; with `old` = v it emits a move and an add)
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x120 + N, 0xF, 0xF, false);
 }
 
 // Sum over the 16 lanes of a DPP row; result in every lane of the row.

@@ -552,7 +552,7 @@ struct Cand { uint32_t i, u, r; };
 
 template <bool MINMODE>
 __device__ __forceinline__ bool cand_better(uint32_t ai, uint32_t au, uint32_t ar, uint32_t bi, uint32_t bu, uint32_t br) {
-    const uint32_t x = ai * bu, y = bi * au;  // < 2^28
+    const uint32_t x = __umul24(ai, bu), y = __umul24(bi, au);  // operands < 2^14 (n_features <= 16384): products < 2^28, full-rate multiplies
     if (MINMODE) return x < y || (x == y && ar < br);
     return x > y || (x == y && ar < br);
 }
@@ -594,25 +594,27 @@ __device__ __forceinline__ Cand node_best(const KCt& k, int& cmp_par, uint32_t n
             // mirrored in LDS, every level streams from L2): 16 passes = 256 rows requested before the first is consumed,
             // instead of one memory round trip per 64 rows.
             if (!fill && rows > 256) {
+                // Blocks of 256 rows (16 passes of the block's 16 rows), double-buffered: the next block's rows are on their
+                // way while this one's are counted - with one block at a time a 1001-row node was four exposed memory round
+                // trips (41 k cycles per level at bf 1000).  Requests are unconditional (rows beyond the node are clamped to
+                // its last row): a conditional request makes the compiler wait for everything outstanding at the join.  A
+                // row's popcount is counted from the row itself (same reduction, high half) instead of loaded, links wait
+                // in registers until their block is consumed.
                 constexpr int NP = 16;
-                for (; r_start + NP * 16 <= rows + NP * 16 - 1 && r_start < rows; r_start += NP * 16) {
-                    u32x4_t d[NP];
-                    uint32_t cd[NP];
+                constexpr uint32_t BLK = NP * 16;
+                u32x4_t dA[NP], dB[NP];
+                uint32_t lkA[NP], lkB[NP];
+                auto issue = [&](u32x4_t (&d)[NP], uint32_t (&lk)[NP], uint32_t rs) {
 #pragma unroll
                     for (int p = 0; p < NP; ++p) {
-                        const uint32_t r = r_start + p * 16 + g;
+                        const uint32_t r = rs + p * 16 + g;
                         const uint32_t rc = r < last ? r : last;
                         d[p] = ldg<u32x4_t>(k.cent + (meta + rc) * 256 + l * 16);
-                        cd[p] = ldg<uint32_t>(k.card + meta + rc);
+                        lk[p] = want_link ? ldg<uint32_t>(k.link + meta + rc) : 0u;
                     }
-                    if (want_link) {
-#pragma unroll
-                        for (int p = 0; p < NP; ++p) {
-                            const uint32_t r = r_start + p * 16 + g;
-                            if (l == 0 && r < rows) s_link[r] = ldg<uint32_t>(k.link + meta + r);
-                        }
-                    }
-                    if (r_start == 0) {
+                };
+                auto consume = [&](const u32x4_t (&d)[NP], const uint32_t (&lk)[NP], uint32_t rs) {
+                    if (rs == 0) {
                         if (load_hdr) {
                             len = uni(hraw.x);
                             leaf = uni(hraw.y);
@@ -622,8 +624,9 @@ __device__ __forceinline__ Cand node_best(const KCt& k, int& cmp_par, uint32_t n
                     }
 #pragma unroll
                     for (int p = 0; p < NP; ++p) {
-                        const uint32_t r = r_start + p * 16 + g;
-                        const uint32_t both = row16_sum(popc4v(d[p] & xv) + (l == 0 ? cd[p] << 16 : 0u));
+                        const uint32_t r = rs + p * 16 + g;
+                        if (want_link && l == 0 && r < rows) s_link[r] = lk[p];
+                        const uint32_t both = row16_sum(popc4v(d[p] & xv) + (popc4v(d[p]) << 16));
                         const uint32_t inter = both & 0xFFFFu;
                         uint32_t un = (both >> 16) + vec_pc - inter;
                         anyc = anyc || (r < len && (both >> 16) != 0);
@@ -634,6 +637,13 @@ __device__ __forceinline__ Cand node_best(const KCt& k, int& cmp_par, uint32_t n
                         bu = take ? un : bu;
                         br = take ? r : br;
                     }
+                };
+                issue(dA, lkA, 0);
+                for (; r_start < rows; r_start += 2 * BLK) {
+                    issue(dB, lkB, r_start + BLK);
+                    consume(dA, lkA, r_start);
+                    issue(dA, lkA, r_start + 2 * BLK);
+                    if (r_start + BLK < rows) consume(dB, lkB, r_start + BLK);
                 }
             }
         }
