@@ -43,17 +43,37 @@ def _one_stream(have: "int | None", new: "int | None") -> "int | None":
 class DevTable:
     r"""A BitFeature buffer table ``[k, n_features + 1]`` of `width`-byte unsigned integers that lives in
     HBM (multiround's round-* tables, reference multiround.py:132-143, without the trip through host
-    memory).  `raw` is a 2-D ``torch.uint8`` tensor of shape (k, (n_features + 1) * width)."""
+    memory).  `raw` is a 2-D ``torch.uint8`` tensor of shape (k_head, (n_features + 1) * width).
 
-    __slots__ = ("raw", "width")
+    **Singleton tail** (uint8 tables only): the rows behind `raw` that are BitFeatures of ONE fingerprint may
+    be held in `tail`, a ``torch.uint8`` tensor (k_tail, n_features / 8) of PACKED rows - such a buffer row is
+    the fingerprint's bits as bytes followed by n_samples = 1, i.e. 2049 bytes that say what 256 do.  The
+    tables multiround produces are sorted by n_samples, largest first (bitbirch.py:1216-1222), so their
+    singletons are exactly a tail - 99 % of the rows on sparse fingerprints that hardly merge.  The table the
+    reference would hold is `raw` followed by the unpacked tail; `numpy()` returns precisely that, and
+    inserting the head as buffers and the tail as fingerprints is the same sequence of BitFeatures
+    (bitbirch.py:412-421 vs :422-448)."""
 
-    def __init__(self, raw: object, width: int) -> None:
+    __slots__ = ("raw", "width", "tail")
+
+    def __init__(self, raw: object, width: int, tail: object = None) -> None:
         self.raw = raw
         self.width = int(width)
+        self.tail = tail if tail is not None and int(tail.shape[0]) > 0 else None  # type: ignore[attr-defined]
+        if self.tail is not None and self.width != 1:
+            raise ValueError("only uint8 tables have a singleton tail")
+
+    @property
+    def n_head(self) -> int:
+        return int(self.raw.shape[0])  # type: ignore[attr-defined]
+
+    @property
+    def n_tail(self) -> int:
+        return 0 if self.tail is None else int(self.tail.shape[0])  # type: ignore[attr-defined]
 
     @property
     def shape(self) -> tuple[int, int]:
-        return int(self.raw.shape[0]), int(self.raw.shape[1]) // self.width  # type: ignore[attr-defined]
+        return self.n_head + self.n_tail, int(self.raw.shape[1]) // self.width  # type: ignore[attr-defined]
 
     @property
     def dtype(self) -> np.dtype:
@@ -61,23 +81,37 @@ class DevTable:
 
     @property
     def nbytes(self) -> int:
-        return int(self.raw.numel())  # type: ignore[attr-defined]
+        r"""Bytes in HBM (what an exchange moves)."""
+        return int(self.raw.numel()) + (0 if self.tail is None else int(self.tail.numel()))  # type: ignore[attr-defined]
 
     def __len__(self) -> int:
         return self.shape[0]
 
     def n_samples(self) -> NDArray[np.integer]:
         r"""The last column (n_samples of every BitFeature) on the host."""
-        k, cols = self.shape
+        k, cols = self.n_head, self.shape[1]
         col = self.raw.view(k, cols, self.width)[:, -1, :].contiguous().cpu().numpy()  # type: ignore[attr-defined]
-        return col.view(self.dtype).reshape(k)
+        col = col.view(self.dtype).reshape(k)
+        if self.tail is not None:
+            col = np.concatenate([col, np.ones(self.n_tail, dtype=self.dtype)])
+        return col
 
     def numpy(self) -> NDArray[np.integer]:
-        k, cols = self.shape
-        return self.raw.cpu().numpy().view(self.dtype).reshape(k, cols)  # type: ignore[attr-defined]
+        k, cols = self.n_head, self.shape[1]
+        head = self.raw.cpu().numpy().view(self.dtype).reshape(k, cols)  # type: ignore[attr-defined]
+        if self.tail is None:
+            return head
+        packed = self.tail.cpu().numpy()  # type: ignore[attr-defined]
+        rows = np.ones((packed.shape[0], cols), dtype=np.uint8)
+        rows[:, :-1] = np.unpackbits(packed, axis=1)[:, : cols - 1]
+        return np.concatenate([head, rows])
 
     def rows(self, lo: int, hi: int) -> "DevTable":
-        return DevTable(self.raw[lo:hi], self.width)  # type: ignore[index]
+        kh = self.n_head
+        tail = None
+        if self.tail is not None and hi > kh:
+            tail = self.tail[max(lo - kh, 0):hi - kh]  # type: ignore[index]
+        return DevTable(self.raw[min(lo, kh):min(hi, kh)], self.width, tail)  # type: ignore[index]
 
 
 class HipEngine:
@@ -211,9 +245,9 @@ class HipEngine:
                     raise RuntimeError("buffers must have shape (k, n_features + 1)")
                 raw = bufs.raw if bufs.raw.is_contiguous() else bufs.raw.contiguous()
                 keep.append(raw)
-                ks.append(bufs.shape[0])
+                ks.append(bufs.n_head)
                 widths.append(bufs.width)
-                ptrs.append(int(raw.data_ptr()) if bufs.shape[0] else None)
+                ptrs.append(int(raw.data_ptr()) if bufs.n_head else None)
                 stream = _one_stream(stream, _launch_stream(raw))
             else:
                 b = np.ascontiguousarray(bufs)
@@ -232,6 +266,12 @@ class HipEngine:
         k_p = (C.c_int64 * k)(*ks)
         out_p = (C.c_void_p * k)(*[o.ctypes.data if o.size else None for o in outs])
         _lib.check(lib.bbh_trees_fit_buffers(handles, k, bufs_p, w_p, k_p, out_p, stream))
+        # singleton tails: the same BitFeatures as packed fingerprints, behind their table's head
+        tails = [(i, b.tail) for i, b in enumerate(bufs_list) if isinstance(b, DevTable) and b.tail is not None]
+        if tails:
+            t_out = HipEngine.fit_packed_many([engines[i] for i, _ in tails], [t for _, t in tails])
+            for (i, _), o in zip(tails, t_out):
+                outs[i] = np.concatenate([outs[i], o])
         return outs
 
     def fit_buffers(self, bufs: "NDArray[np.integer] | DevTable", stream: int | None = None) -> NDArray[np.uint32]:
@@ -241,12 +281,14 @@ class HipEngine:
             if bufs.shape[1] != self.n_features + 1:
                 raise RuntimeError("buffers must have shape (k, n_features + 1)")
             raw = bufs.raw if bufs.raw.is_contiguous() else bufs.raw.contiguous()
-            k = bufs.shape[0]
+            k = bufs.n_head
             out = np.empty(k, dtype=np.uint32)
             if k:
                 _lib.check(self._lib.bbh_tree_fit_buffers(
                     self._h, int(raw.data_ptr()), bufs.width, k, out.ctypes.data,
                     _launch_stream(raw) if stream is None else stream))
+            if bufs.tail is not None:  # the singleton tail: packed fingerprints (same BitFeatures, see DevTable)
+                out = np.concatenate([out, self.fit_packed(bufs.tail, stream)])
             return out
         bufs = np.ascontiguousarray(bufs)
         if bufs.ndim != 2 or bufs.shape[1] != self.n_features + 1:
@@ -290,18 +332,27 @@ class HipEngine:
         )
         return ids, ns, cents, ls
 
-    def gather_buffers(self, positions: NDArray[np.int64], width: int, device_out: bool = False) -> "NDArray[np.integer] | DevTable":
+    def gather_buffers(self, positions: NDArray[np.int64], width: int, device_out: bool = False,
+                       n_tail: int = 0) -> "NDArray[np.integer] | DevTable":
         r"""BitFeature buffer rows of the leaves at `positions` (chain order); `device_out`: the table
-        is produced in HBM and stays there (`DevTable`)."""
+        is produced in HBM and stays there (`DevTable`).  `n_tail` (device tables of width 1): the last n_tail
+        positions are BitFeatures of one fingerprint and are kept as packed rows (`DevTable.tail`)."""
         pos = np.ascontiguousarray(positions, dtype=np.int64)
         if device_out:
             import torch
 
-            raw = torch.empty((pos.size, (self.n_features + 1) * width), dtype=torch.uint8,
-                              device=torch.device("cuda", self.device))
-            if pos.size:
-                _lib.check(self._lib.bbh_tree_gather_buffers(self._h, pos.ctypes.data, pos.size, width, int(raw.data_ptr())))
-            return DevTable(raw, width)
+            dev = torch.device("cuda", self.device)
+            n_tail = int(n_tail) if width == 1 else 0
+            kh = pos.size - n_tail
+            raw = torch.empty((kh, (self.n_features + 1) * width), dtype=torch.uint8, device=dev)
+            if kh:
+                _lib.check(self._lib.bbh_tree_gather_buffers(self._h, pos.ctypes.data, kh, width, int(raw.data_ptr())))
+            tail = None
+            if n_tail:
+                tail = torch.empty((n_tail, self.nbytes), dtype=torch.uint8, device=dev)
+                tpos = np.ascontiguousarray(pos[kh:])
+                _lib.check(self._lib.bbh_tree_gather_centroids(self._h, tpos.ctypes.data, n_tail, int(tail.data_ptr())))
+            return DevTable(raw, width, tail)
         out = np.empty((pos.size, self.n_features + 1), dtype=_WIDTH_DTYPES[width])
         if pos.size:
             _lib.check(

@@ -58,6 +58,7 @@ _PROTOTYPES = {
     "bbh_tree_leaf_count": (_int, [_vp, C.POINTER(_i64)]),
     "bbh_tree_export_leaves": (_int, [_vp, _vp, _vp, _vp, _vp, _i32]),
     "bbh_tree_gather_buffers": (_int, [_vp, _vp, _i64, _i32, _vp]),
+    "bbh_tree_gather_centroids": (_int, [_vp, _vp, _i64, _vp]),
     "bbh_tree_stats": (_int, [_vp, _vp]),
     "bbh_profile_enable": (_int, [_int]),
     "bbh_profile_reset": (_int, []),

@@ -684,7 +684,11 @@ class BitBirch:
         dev_ok = device and getattr(self._engine, "device_tables", False)
         for name, pos in self._group_positions(positions).items():
             if dev_ok:
-                bufs[name] = self._engine.gather_buffers(pos, np.dtype(name).itemsize, device_out=True)
+                n_tail = 0
+                if name == "uint8":  # the run of one-fingerprint BitFeatures the table ends with stays packed (DevTable.tail)
+                    ones = lv["n"][pos] == 1
+                    n_tail = int(ones.size if ones.all() else np.argmax(~ones[::-1]))
+                bufs[name] = self._engine.gather_buffers(pos, np.dtype(name).itemsize, device_out=True, n_tail=n_tail)
             else:
                 bufs[name] = self._engine.gather_buffers(pos, np.dtype(name).itemsize)
             beg, end = lv["beg"][pos], lv["end"][pos]
@@ -701,17 +705,21 @@ class BitBirch:
         initial_mol: int = 0,
         input_is_packed: bool = True,
         n_largest: int = 1,
+        device: bool = False,
     ) -> tuple[dict[str, NDArray[np.integer]], dict[str, _IndexLists]]:
         r"""`_bf_to_np_refine` (bitbirch.py:1224-1290) in array form: the `n_largest`
         biggest leaves are exploded into singleton uint8 buffers rebuilt from the
-        original fingerprints and appended to the uint8 group, after the survivors."""
+        original fingerprints and appended to the uint8 group, after the survivors.
+        `device`: the tables stay in HBM (`DevTable`; the exploded fingerprints join the uint8 table's packed
+        singleton tail) when the engine can do that and the input is packed."""
         order = self._leaf_order(True)
+        dev_ok = device and input_is_packed and getattr(self._engine, "device_tables", False)
         if n_largest == 0:
-            return self._bf_tables(order)
+            return self._bf_tables(order, device=dev_ok)
         if n_largest < 1:
             raise ValueError("n_largest must be >= 1")
         largest, rest = order[:n_largest], order[n_largest:]
-        bufs, mols = self._bf_tables(rest)
+        bufs, mols = self._bf_tables(rest, device=dev_ok)
         F = self._n_features
         big_rows: list[NDArray[np.uint8]] = []
         big_ids: list[NDArray[np.int64]] = []
@@ -730,15 +738,41 @@ class BitBirch:
             elif hasattr(X, "data_ptr") and getattr(X, "is_cuda", False):  # device-resident shard
                 import torch
 
-                fps = X[torch.from_numpy(arr_idxs).to(X.device)].cpu().numpy()
+                fps = X[torch.from_numpy(arr_idxs).to(X.device)]
+                if not dev_ok:
+                    fps = fps.cpu().numpy()
             else:
                 fps = np.asarray(X)[arr_idxs]
+            if dev_ok:
+                big_rows.append(fps)  # packed rows: they go into the table's singleton tail as they are
+                big_ids.append(mol_idxs)
+                continue
             fps = np.asarray(fps)
             if input_is_packed:
                 fps = unpack_fingerprints(fps.astype(np.uint8, copy=False), F)
             big_rows.append(fps.astype(np.uint8))
             big_ids.append(mol_idxs)
-        if big_rows:
+        if big_rows and dev_ok:
+            import torch
+
+            from bblean_amd._engine import DevTable
+
+            tdev = torch.device("cuda", self._engine.device)
+            parts = [r if hasattr(r, "data_ptr") else torch.from_numpy(np.ascontiguousarray(r, dtype=np.uint8)).to(tdev) for r in big_rows]
+            ids = np.concatenate(big_ids)
+            ones = np.ones(ids.size, dtype=np.int64)
+            if "uint8" in bufs:
+                tab = bufs["uint8"]
+                if tab.tail is not None:
+                    parts = [tab.tail] + parts
+                bufs["uint8"] = DevTable(tab.raw, 1, torch.cat(parts) if len(parts) > 1 else parts[0])
+                old = mols["uint8"]
+                mols["uint8"] = _IndexLists(np.concatenate([old.counts, ones]), np.concatenate([old.flat, ids]))
+            else:
+                empty = torch.empty((0, F + 1), dtype=torch.uint8, device=tdev)
+                bufs["uint8"] = DevTable(empty, 1, torch.cat(parts) if len(parts) > 1 else parts[0])
+                mols["uint8"] = _IndexLists(ones, ids)
+        elif big_rows:
             rows = np.concatenate(big_rows)
             extra = np.empty((rows.shape[0], F + 1), dtype=np.uint8)
             extra[:, :-1] = rows

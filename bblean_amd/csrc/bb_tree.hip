@@ -344,6 +344,11 @@ __device__ __forceinline__ void block_sum_fused(const KCt& k, int& red_slot, boo
 // packed fingerprint's is not written, and no reader looks at it.  The first merge writes the sum of the two members
 // there.  Readers are handed an EFFECTIVE slot word with tier TIER_LAZY (never stored) and the centroid row (`crow`).
 constexpr uint32_t TIER_LAZY = 3u;
+// ... and since round 4 such a BitFeature has no uint8 slot at all: its slot word is SLOT_LAZY8 (slot 0 of the uint8 pool,
+// which no BitFeature ever owns: the counter starts at 1, so a speculative load through the word stays inside the pool);
+// the slot is allocated by the merge that gives it a second member.  A tree of N fingerprints that hardly merge (S-ecfp:
+// 99 % singletons) used to reserve 2 KB x N of HBM that nothing ever wrote.
+constexpr uint32_t SLOT_LAZY8 = 0u;
 __device__ __forceinline__ uint32_t slot_effective(uint32_t slotw, u64 n) { return n == 1 ? ((TIER_LAZY << 30) | (slotw & 0x3FFFFFFFu)) : slotw; }
 __device__ __forceinline__ void byte_to_cols(uint32_t byte, uint32_t v[8]) {
 #pragma unroll
@@ -1613,11 +1618,13 @@ __device__ __forceinline__ void tree_insert_body(unsigned char* smem_raw, TreeDe
         if (root_len == 0) {
             // ---- very first element of an empty tree: row 0 of the root leaf -------------
             const uint32_t tier = tier_for(el.nS);
-            const bool lazy = !bufmode && el.nS == 1;  // a packed fingerprint: its cluster features are its centroid, nothing to write
+            const bool lazy = el.nS == 1;  // one member: its cluster features are its centroid, no slot and nothing to write
             const uint32_t s = alloc_n<SUB>(k, cI, gctr + C_IDS, 1, 14);
-            const uint32_t slotw = (tier << 30) | (tier == 0 ? alloc_n<SUB>(k, c8, gctr + C_N8, 1, 15)
-                                                 : (tier == 1 ? alloc_n<SUB>(k, c16, gctr + C_N16, 1, 15)
-                                                              : alloc_n<SUB>(k, c32, gctr + C_N32, 1, 15)));
+            uint32_t slotw = SLOT_LAZY8;
+            if (!lazy)
+                slotw = (tier << 30) | (tier == 0 ? alloc_n<SUB>(k, c8, gctr + C_N8, 1, 15)
+                                                  : (tier == 1 ? alloc_n<SUB>(k, c16, gctr + C_N16, 1, 15)
+                                                               : alloc_n<SUB>(k, c32, gctr + C_N32, 1, 15)));
             if (tid == 0) {
                 stg<uint32_t>(k.hdr + root, 1u);
                 stats[3]++;
@@ -1807,6 +1814,8 @@ __device__ __forceinline__ void tree_insert_body(unsigned char* smem_raw, TreeDe
                 if (new_tier != old_tier) {
                     slotN = (new_tier << 30) | (new_tier == 1 ? alloc_n<SUB>(k, c16, gctr + C_N16, 1, 15)
                                                               : alloc_n<SUB>(k, c32, gctr + C_N32, 1, 15));
+                } else if (nT == 1) {
+                    slotN = alloc_n<SUB>(k, c8, gctr + C_N8, 1, 15);  // the second member: the BitFeature gets its uint8 row (SLOT_LAZY8)
                 }
                 uint8_t* crow = k.cent + (leafm + jl) * (size_t)k.RB;
                 u64 card = pcs[0];
@@ -1857,11 +1866,13 @@ __device__ __forceinline__ void tree_insert_body(unsigned char* smem_raw, TreeDe
             } else {
                 // append_subcluster (bitbirch.py:284-287): new leaf BitFeature
                 const uint32_t tier = tier_for(el.nS);
-                const bool lazy = !bufmode && el.nS == 1;  // (its cluster features are its centroid: nothing to write)
+                const bool lazy = el.nS == 1;  // (one member: its cluster features are its centroid, no slot and nothing to write)
                 const uint32_t s = alloc_n<SUB>(k, cI, gctr + C_IDS, 1, 14);
-                const uint32_t slotw = (tier << 30) | (tier == 0 ? alloc_n<SUB>(k, c8, gctr + C_N8, 1, 15)
-                                                     : (tier == 1 ? alloc_n<SUB>(k, c16, gctr + C_N16, 1, 15)
-                                                                  : alloc_n<SUB>(k, c32, gctr + C_N32, 1, 15)));
+                uint32_t slotw = SLOT_LAZY8;
+                if (!lazy)
+                    slotw = (tier << 30) | (tier == 0 ? alloc_n<SUB>(k, c8, gctr + C_N8, 1, 15)
+                                                      : (tier == 1 ? alloc_n<SUB>(k, c16, gctr + C_N16, 1, 15)
+                                                                   : alloc_n<SUB>(k, c32, gctr + C_N32, 1, 15)));
                 if (tid == 0) {
                     stg<uint32_t>(k.hdr + leafnode, leaflen + 1);
                     stats[3]++;
@@ -2317,6 +2328,7 @@ struct bbh_tree {
     std::vector<uint32_t> chain_nodes, chain_rows;
     uint32_t *d_chain_nodes = nullptr, *d_chain_rows = nullptr;
     size_t d_chain_cap = 0;
+    int64_t unsup_stretch = 0;  // elements the steady-state kernel took after the pipelined one last refused the tree's shape
 };
 
 namespace {
@@ -2332,9 +2344,24 @@ int grow_pool(T*& p, size_t used_elems, size_t new_elems) {
     return BBH_OK;
 }
 
+// BBHIP_TINY_POOLS=1 (tests): pools are pre-grown by next to nothing, so that the kernels run out of nodes / cluster-feature
+// slots in the middle of their runs and every STOP_* -> grow -> relaunch path is exercised
+static bool tiny_pools() {
+    static const bool on = [] { const char* v = getenv("BBHIP_TINY_POOLS"); return v != nullptr && v[0] != '\0' && std::strcmp(v, "0") != 0; }();
+    return on;
+}
+// a pool that has to grow grows by at least half (a tree fed in 64 MiB slabs asked for a slightly larger pool with every
+// slab, i.e. copied all of it every time); `hint` is what the caller expects to need
+static uint32_t grow_target(uint32_t cap, uint32_t want) {
+    if (tiny_pools()) return want;
+    const uint64_t geo = (uint64_t)cap + cap / 2;
+    return (uint32_t)std::min<uint64_t>(0x3FFFFFFFull, std::max<uint64_t>(want, geo));
+}
+
 int grow_nodes(bbh_tree* t, uint32_t want) {
     TreeDev& h = t->h;
     if (want <= h.cap_nodes) return BBH_OK;
+    want = grow_target(h.cap_nodes, want);
     const size_t rows = (size_t)h.bf + 1;
     // a tree that has not received anything yet owns one empty root: nothing to carry over but its
     // 16-byte header (a multiround round creates hundreds of trees and grows each of them once)
@@ -2358,12 +2385,15 @@ int grow_cf(bbh_tree* t, int tier, uint32_t want) {
     TreeDev& h = t->h;
     const size_t F = (size_t)h.F;
     if (tier == 0 && want > h.cap8) {
+        want = grow_target(h.cap8, want);
         BB_TRY(grow_pool(h.cf8, (size_t)std::min(h.cap8, h.ctr[C_N8]) * F, (size_t)want * F));
         h.cap8 = want;
     } else if (tier == 1 && want > h.cap16) {
+        want = grow_target(h.cap16, want);
         BB_TRY(grow_pool(h.cf16, (size_t)std::min(h.cap16, h.ctr[C_N16]) * F, (size_t)want * F));
         h.cap16 = want;
     } else if (tier == 2 && want > h.cap32) {
+        want = grow_target(h.cap32, want);
         BB_TRY(grow_pool(h.cf32, (size_t)std::min(h.cap32, h.ctr[C_N32]) * F, (size_t)want * F));
         h.cap32 = want;
     }
@@ -2392,6 +2422,7 @@ int init_empty(bbh_tree* t) {
     root.len = 0; root.leaf = 1; root.prev = NONE; root.next = NONE;
     BB_HIP(hipMemcpy(h.node_hdr, &root, sizeof(root), hipMemcpyHostToDevice));
     h.ctr[C_NODES] = 1;
+    h.ctr[C_N8] = 1;  // (slot 0 of the uint8 pool is SLOT_LAZY8: never a BitFeature's)
     h.ctr[C_ROOT] = 0;
     h.ctr[C_FIRST_LEAF] = 0;
     h.ctr[C_DEPTH] = 1;
@@ -2488,6 +2519,28 @@ static bool dense_launch(size_t n_trees, size_t lds_bytes) {
 
 uint32_t clamp30(uint64_t v) { return (uint32_t)std::min<uint64_t>(0x3FFFFFFFull, v); }
 
+// Pools are grown BEFORE a call to what its n elements are expected to need; a kernel that runs out anyway stops in front of
+// the element that does not fit (STOP_NODES / STOP_CF*) and the host grows the pool and relaunches (run_insert_multi).
+//   uint8 cluster features: a slot is taken by the merge that gives a BitFeature its second member (SLOT_LAZY8) and by an
+//   appended buffer of several members - an eighth of the elements is more than any workload measured took (S-fake 3 %,
+//   S-ecfp 1 %, S-rdkit-like 10 %); nodes: one per bf / 2 elements (a node is half full after its split); tracking cluster
+//   features (uint32): two per node split.
+int pregrow(bbh_tree* t, int64_t n, int width) {
+    TreeDev& h = t->h;
+    if (tiny_pools()) {
+        BB_TRY(grow_cf(t, 0, clamp30((uint64_t)h.ctr[C_N8] + 8)));
+        BB_TRY(grow_cf(t, 1, clamp30((uint64_t)h.ctr[C_N16] + 8)));
+        BB_TRY(grow_nodes(t, clamp30((uint64_t)h.ctr[C_NODES] + 8 + h.ctr[C_DEPTH])));
+        BB_TRY(grow_cf(t, 2, clamp30((uint64_t)h.ctr[C_N32] + 16 + 2 * (uint64_t)h.ctr[C_DEPTH])));
+        return BBH_OK;
+    }
+    if (width <= 1) BB_TRY(grow_cf(t, 0, clamp30((uint64_t)h.ctr[C_N8] + (uint64_t)n / 8 + 1024)));
+    if (width == 2) BB_TRY(grow_cf(t, 1, clamp30((uint64_t)h.ctr[C_N16] + (uint64_t)n + 64)));
+    BB_TRY(grow_nodes(t, clamp30((uint64_t)h.ctr[C_NODES] + (uint64_t)n / std::max(1, h.bf / 2) + 64)));
+    BB_TRY(grow_cf(t, 2, clamp30((uint64_t)h.ctr[C_N32] + (uint64_t)n / std::max(1, h.bf / 6) + 256)));
+    return BBH_OK;
+}
+
 // One insertion job: a tree and the elements to insert into it.
 struct Job {
     bbh_tree* t;
@@ -2536,7 +2589,10 @@ int run_insert_multi(std::vector<Job>& jobs, hipStream_t s) {
         }
         TreeDev* dptr = single ? jobs[0].t->d : darr;
         size_t prof_tok = (size_t)-1;
-        static const bool launch_log = getenv("BBHIP_LAUNCH_LOG") != nullptr;  // one line per launch on stderr (tools/)
+        static const bool launch_log = [] {  // one line per launch on stderr (tools/); unset, empty or "0": off
+            const char* v = getenv("BBHIP_LAUNCH_LOG");
+            return v != nullptr && v[0] != '\0' && std::strcmp(v, "0") != 0;
+        }();
         const auto log_t0 = std::chrono::steady_clock::now();
         const char* log_kernel = "complete";
         uint64_t log_before[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -2666,7 +2722,8 @@ int run_insert_multi(std::vector<Job>& jobs, hipStream_t s) {
             if (j.stalls > 3) { rc = bb::fail(BBH_ERR_CAPACITY, "tree engine made no progress (stop reason %d)", back.stop_reason); break; }
             const int64_t left = j.n - j.done;
             auto more = [&](uint32_t used, uint32_t cap, int64_t per_elem_hint) -> uint32_t {
-                uint64_t want = (uint64_t)cap * 2;
+                if (tiny_pools()) return clamp30((uint64_t)cap + 8 + 2 * (uint64_t)h.ctr[C_DEPTH]);  // (one insertion's worst case fits)
+                uint64_t want = (uint64_t)cap + cap / 2;  // (grow_target's minimum; a pool of tens of GB is not doubled)
                 uint64_t est = (uint64_t)used + (uint64_t)(left * per_elem_hint) / 4 + 4096;
                 if (est > want) want = est;
                 if (want > 0x3FFFFFFFull) want = 0x3FFFFFFFull;
@@ -2675,12 +2732,18 @@ int run_insert_multi(std::vector<Job>& jobs, hipStream_t s) {
             switch (back.stop_reason) {
                 case STOP_DONE: break;
                 case STOP_NODES: rc = grow_nodes(t, more(h.ctr[C_NODES], h.cap_nodes, 1)); break;
-                case STOP_CF8: rc = grow_cf(t, 0, more(h.ctr[C_N8], h.cap8, 4)); break;
+                case STOP_CF8: rc = grow_cf(t, 0, more(h.ctr[C_N8], h.cap8, 1)); break;
                 case STOP_CF16: rc = grow_cf(t, 1, more(h.ctr[C_N16], h.cap16, 1)); break;
                 case STOP_CF32: rc = grow_cf(t, 2, more(h.ctr[C_N32], h.cap32, 1)); break;
                 case STOP_DEPTH: rc = bb::fail(BBH_ERR_CAPACITY, "tree deeper than %d levels (or corrupt link)", MAXD); break;
                 case STOP_RANGE: rc = bb::fail(BBH_ERR_INVALID, "n_samples exceeds 2^32-1 (engine limit)"); break;
-                case STOP_PIPE_UNSUPPORTED: j.old_left = 8192; break;  // a stretch on the steady-state kernel, then the pipeline again
+                case STOP_PIPE_UNSUPPORTED:
+                    // a stretch on the steady-state kernel, then the pipeline again.  A tree that keeps its unsupported shape
+                    // would pay a launch that inserts nothing after every stretch: the stretch doubles (up to 4 M elements)
+                    // while the pipeline makes no progress and starts again at 8 192 as soon as it does
+                    t->unsup_stretch = back.processed > 0 || t->unsup_stretch == 0 ? 8192 : std::min<int64_t>(t->unsup_stretch * 2, 1ll << 22);
+                    j.old_left = t->unsup_stretch;
+                    break;
                 case STOP_INTERNAL: rc = bb::fail(BBH_ERR_HIP, "pipelined kernel: a wait gave up (internal error)"); break;
                 default: rc = bb::fail(BBH_ERR_HIP, "unknown stop reason %d", back.stop_reason); break;
             }
@@ -2887,10 +2950,7 @@ extern "C" int bbh_tree_fit_packed(bbh_tree* t, const uint8_t* rows, int64_t n, 
     if (n == 0) return BBH_OK;
     BB_HIP(hipSetDevice(t->device));
     hipStream_t s = (hipStream_t)stream;
-    // every fingerprint can become a new leaf BitFeature at tier 0
-    BB_TRY(grow_cf(t, 0, clamp30((uint64_t)t->h.ctr[C_N8] + (uint64_t)n + 64)));
-    BB_TRY(grow_nodes(t, clamp30((uint64_t)t->h.ctr[C_NODES] + (uint64_t)n / std::max(1, t->h.bf / 3) + 64)));
-    BB_TRY(grow_cf(t, 2, clamp30((uint64_t)t->h.ctr[C_N32] + (uint64_t)n / std::max(1, t->h.bf / 6) + 256)));
+    BB_TRY(pregrow(t, n, 0));
     bb::DevOut o;
     BB_TRY(o.init(out_leaf, (size_t)n * 4));
     const char* benv = getenv("BBHIP_BATCH");
@@ -2970,10 +3030,7 @@ extern "C" int bbh_tree_fit_buffers(bbh_tree* t, const void* bufs, int32_t width
     if (k == 0) return BBH_OK;
     BB_HIP(hipSetDevice(t->device));
     hipStream_t s = (hipStream_t)stream;
-    if (width == 1) BB_TRY(grow_cf(t, 0, clamp30((uint64_t)t->h.ctr[C_N8] + (uint64_t)k + 64)));
-    if (width == 2) BB_TRY(grow_cf(t, 1, clamp30((uint64_t)t->h.ctr[C_N16] + (uint64_t)k + 64)));
-    BB_TRY(grow_nodes(t, clamp30((uint64_t)t->h.ctr[C_NODES] + (uint64_t)k / std::max(1, t->h.bf / 3) + 64)));
-    BB_TRY(grow_cf(t, 2, clamp30((uint64_t)t->h.ctr[C_N32] + (uint64_t)k / std::max(1, t->h.bf / 6) + 256)));
+    BB_TRY(pregrow(t, k, width));
     const size_t row_bytes = ((size_t)t->h.F + 1) * width;
     bb::DevOut o;
     BB_TRY(o.init(out_leaf, (size_t)k * 4));
@@ -3037,9 +3094,7 @@ extern "C" int bbh_trees_fit_packed(bbh_tree** trees, int32_t n_trees, const uin
         if (!t || t->device != device) return bb::fail(BBH_ERR_INVALID, "all trees of one call must live on one device");
         if (n[i] < 0 || row_stride[i] < t->h.nbytes) return bb::fail(BBH_ERR_INVALID, "rows must be (n, n_features/8) uint8");
         if (n[i] == 0) continue;
-        BB_TRY(grow_cf(t, 0, clamp30((uint64_t)t->h.ctr[C_N8] + (uint64_t)n[i] + 64)));
-        BB_TRY(grow_nodes(t, clamp30((uint64_t)t->h.ctr[C_NODES] + (uint64_t)n[i] / std::max(1, t->h.bf / 3) + 64)));
-        BB_TRY(grow_cf(t, 2, clamp30((uint64_t)t->h.ctr[C_N32] + (uint64_t)n[i] / std::max(1, t->h.bf / 6) + 256)));
+        BB_TRY(pregrow(t, n[i], 0));
         BB_TRY(ins[(size_t)i].init(rows[i], (size_t)(n[i] * row_stride[i]), s));
         BB_TRY(outs[(size_t)i].init(out_leaf ? out_leaf[i] : nullptr, (size_t)n[i] * 4));
         jobs.push_back(Job{t, (const uint8_t*)ins[(size_t)i].dev, row_stride[i], nullptr, 0, n[i],
@@ -3070,10 +3125,7 @@ extern "C" int bbh_trees_fit_buffers(bbh_tree** trees, int32_t n_trees, const vo
         if (w != 1 && w != 2 && w != 4 && w != 8) return bb::fail(BBH_ERR_INVALID, "buffer element width must be 1, 2, 4 or 8");
         if (k[i] < 0) return bb::fail(BBH_ERR_INVALID, "negative buffer count");
         if (k[i] == 0) continue;
-        if (w == 1) BB_TRY(grow_cf(t, 0, clamp30((uint64_t)t->h.ctr[C_N8] + (uint64_t)k[i] + 64)));
-        if (w == 2) BB_TRY(grow_cf(t, 1, clamp30((uint64_t)t->h.ctr[C_N16] + (uint64_t)k[i] + 64)));
-        BB_TRY(grow_nodes(t, clamp30((uint64_t)t->h.ctr[C_NODES] + (uint64_t)k[i] / std::max(1, t->h.bf / 3) + 64)));
-        BB_TRY(grow_cf(t, 2, clamp30((uint64_t)t->h.ctr[C_N32] + (uint64_t)k[i] / std::max(1, t->h.bf / 6) + 256)));
+        BB_TRY(pregrow(t, k[i], w));
         const size_t row_bytes = ((size_t)t->h.F + 1) * (size_t)w;
         BB_TRY(ins[(size_t)i].init(bufs[i], (size_t)k[i] * row_bytes, s));
         BB_TRY(outs[(size_t)i].init(out_leaf ? out_leaf[i] : nullptr, (size_t)k[i] * 4));
@@ -3130,10 +3182,8 @@ extern "C" int bbh_tree_export_leaves(bbh_tree* t, uint32_t* leaf_ids, uint64_t*
                   packed_centroids, n_samples, leaf_ids);
 }
 
-extern "C" int bbh_tree_gather_buffers(bbh_tree* t, const int64_t* positions, int64_t m, int32_t width, void* out) {
-    if (!t || (m > 0 && (!positions || !out))) return bb::fail(BBH_ERR_INVALID, "null argument");
-    if (width != 1 && width != 2 && width != 4 && width != 8) return bb::fail(BBH_ERR_INVALID, "width must be 1, 2, 4 or 8");
-    if (m == 0) return BBH_OK;
+// leaves at `positions` (chain order): BitFeature buffer rows (`bufs`, width bytes per value) and / or packed centroid rows
+static int gather_positions(bbh_tree* t, const int64_t* positions, int64_t m, int32_t width, void* bufs, uint8_t* cents) {
     BB_HIP(hipSetDevice(t->device));
     BB_TRY(build_chain(t));
     const int64_t k = (int64_t)t->chain_nodes.size();
@@ -3149,11 +3199,24 @@ extern "C" int bbh_tree_gather_buffers(bbh_tree* t, const int64_t* positions, in
     int rc = BBH_OK;
     if (hipMemcpy(dn, nodes.data(), (size_t)m * 4, hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(dr, rows.data(), (size_t)m * 4, hipMemcpyHostToDevice) != hipSuccess)
-        rc = bb::fail(BBH_ERR_HIP, "gather_buffers: H2D failed");
-    if (rc == BBH_OK) rc = gather(t, dn, dr, m, width, out, 0, nullptr, nullptr, nullptr);
+        rc = bb::fail(BBH_ERR_HIP, "gather: H2D failed");
+    if (rc == BBH_OK) rc = gather(t, dn, dr, m, width, bufs, 0, cents, nullptr, nullptr);
     (void)bb::dev_free(dn);
     (void)bb::dev_free(dr);
     return rc;
+}
+
+extern "C" int bbh_tree_gather_buffers(bbh_tree* t, const int64_t* positions, int64_t m, int32_t width, void* out) {
+    if (!t || (m > 0 && (!positions || !out))) return bb::fail(BBH_ERR_INVALID, "null argument");
+    if (width != 1 && width != 2 && width != 4 && width != 8) return bb::fail(BBH_ERR_INVALID, "width must be 1, 2, 4 or 8");
+    if (m == 0) return BBH_OK;
+    return gather_positions(t, positions, m, width, out, nullptr);
+}
+
+extern "C" int bbh_tree_gather_centroids(bbh_tree* t, const int64_t* positions, int64_t m, uint8_t* out) {
+    if (!t || (m > 0 && (!positions || !out))) return bb::fail(BBH_ERR_INVALID, "null argument");
+    if (m == 0) return BBH_OK;
+    return gather_positions(t, positions, m, 0, nullptr, out);
 }
 
 extern "C" int bbh_tree_stats(bbh_tree* t, uint64_t* out8) {

@@ -133,7 +133,7 @@ def _initial_rounds(
         if refinement == "none":
             out.extend(t._bf_tables(t._leaf_order(True), device=device_tables) for t in trees)
             continue
-        tabs = [t._refine_tables(f, initial_mol=s, input_is_packed=input_is_packed) for t, (_, f, s, _) in zip(trees, part)]
+        tabs = [t._refine_tables(f, initial_mol=s, input_is_packed=input_is_packed, device=device_tables) for t, (_, f, s, _) in zip(trees, part)]
         if refinement == "full":
             for t in trees:
                 t.reset()
@@ -362,15 +362,18 @@ class _Exchange:
     def _wire(self, a: tp.Any) -> tp.Any:
         import torch
 
-        if hasattr(a, "raw"):  # DevTable
-            t = a.raw.reshape(-1)
-        else:
-            t = torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1))
+        t = a.reshape(-1) if hasattr(a, "data_ptr") else torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1))
         return t if t.device == self.tdev else t.to(self.tdev)
+
+    def _wire_table(self, table: tp.Any) -> list[tp.Any]:
+        r"""The tensors a table travels as: its rows, and - a `DevTable` with a packed singleton tail - the tail."""
+        if hasattr(table, "raw"):  # DevTable
+            return [self._wire(table.raw)] + ([self._wire(table.tail)] if table.tail is not None else [])
+        return [self._wire(table)]
 
     def _plan(self, mine: list[Entry], bin_size: int | None) -> list[list[tuple]]:
         r"""Steps 1 and 2: the descriptor all-gather and the batches every rank derives from it.  A plan entry is
-        (key, src rank, src position, label, name, rows, columns, member ids)."""
+        (key, src rank, src position, label, name, rows, columns, member ids, rows of the packed singleton tail)."""
         import torch
 
         dist, world = self.dist, self.world
@@ -379,22 +382,22 @@ class _Exchange:
         dist.all_gather(cnts, cnt)
         counts = [int(c.item()) for c in cnts]
         cap = max(max(counts), 1)
-        desc = torch.zeros((cap, 6), dtype=torch.int64)
+        desc = torch.zeros((cap, 7), dtype=torch.int64)
         for i, (lab, name, table, idx) in enumerate(mine):
             if not lab.isdigit():
                 raise ValueError(f"table labels must be numeric, got {lab!r}")
             desc[i] = torch.tensor([int(lab), len(lab), _CODE[name], int(table.shape[0]), int(table.shape[1]),
-                                    int(idx.flat.size)], dtype=torch.int64)
+                                    int(idx.flat.size), int(getattr(table, "n_tail", 0))], dtype=torch.int64)
         desc = desc.to(self.tdev)
-        all_desc = [torch.zeros((cap, 6), dtype=torch.int64, device=self.tdev) for _ in range(world)]
+        all_desc = [torch.zeros((cap, 7), dtype=torch.int64, device=self.tdev) for _ in range(world)]
         dist.all_gather(all_desc, desc)
         plan = []
         for r in range(world):
             rows = all_desc[r].cpu().numpy()
             for i in range(counts[r]):
-                lab_i, lab_w, bits, k, cols, nids = (int(v) for v in rows[i])
+                lab_i, lab_w, bits, k, cols, nids, ntail = (int(v) for v in rows[i])
                 lab, name = str(lab_i).zfill(lab_w), _NAME[bits]
-                plan.append((_entry_key(lab, name), r, i, lab, name, k, cols, nids))
+                plan.append((_entry_key(lab, name), r, i, lab, name, k, cols, nids, ntail))
         plan.sort(key=lambda e: e[0])
         return [plan] if bin_size is None else [list(c) for c in batched(plan, bin_size)]
 
@@ -405,8 +408,8 @@ class _Exchange:
         to the tree built from them does not fit 288 GB at 100 M rows that hardly merge).  Every batch's tables are cut,
         in insertion order, into chunks of rows of at most `budget_bytes` and packed into slabs of at most that size;
         slab s + 1 of every batch is on the wire (one grouped `batch_isend_irecv` per step, the same sequence of steps on
-        all ranks) while slab s is inserted, so the merging rank holds two slabs and its trees, nothing else.  The member
-        lists of a table (8 bytes per molecule) travel with its first chunk.  `widest_first`: the merge rounds' order
+        all ranks) while slab s is inserted, so the merging rank holds two slabs, its trees and - on the host - the member lists of the tables whose
+        chunks are still arriving (8 bytes per molecule, they travel with a table's first chunk and are dropped with its last).  `widest_first`: the merge rounds' order
         inside a batch, uint16 tables before uint8 (multiround.py:104-111).  Returns ([(batch, tree) for the batches
         this rank merges], number of batches); same trees as `run` + `_merge_rounds`, chunk for chunk the same stream."""
         import torch
@@ -424,12 +427,13 @@ class _Exchange:
             cur_bytes = 0
             out: list[list[tuple]] = []
             for ent in chunk:
-                _, _, _, _, name, k, cols, _ = ent
-                row_bytes = cols * np.dtype(name).itemsize
-                per = max(1, budget_bytes // max(row_bytes, 1))
+                _, _, _, _, name, k, cols, _, ntail = ent
+                kh = k - ntail  # rows [kh, k): the packed singleton tail (a chunk lies on one side of kh)
                 a = 0
                 while a < k or (k == 0 and a == 0):
-                    b_ = min(k, a + per)
+                    row_bytes = cols * np.dtype(name).itemsize if a < kh or k == 0 else (cols - 1) // 8
+                    per = max(1, budget_bytes // max(row_bytes, 1))
+                    b_ = min(kh if a < kh else k, a + per)
                     nb = (b_ - a) * row_bytes
                     if cur and cur_bytes + nb > budget_bytes:
                         out.append(cur)
@@ -447,33 +451,35 @@ class _Exchange:
         members: dict[tuple[int, str], _IndexLists] = {}   # (batch, key) -> the table's member lists, once its first chunk is here
         offsets: dict[tuple[int, str], NDArray[np.int64]] = {}
         n_steps = max((len(x) for x in slabs), default=0)
+        cols_of: dict[tuple[int, int], int] = {}  # received chunks of a packed singleton tail -> columns of their table
 
-        def post(step: int) -> tuple[list, dict]:
-            ops, got = [], {}
+        def post(step: int) -> tuple[list, dict, list]:
+            ops, got, keep = [], {}, []  # keep: send buffers, alive until the step's requests are done
+            cols_of.clear()
             for b, sl in enumerate(slabs):
                 if step >= len(sl):
                     continue
                 dst = owner(b)
                 for pos, (ent, a, b_, first) in enumerate(sl[step]):
-                    key, src, i, lab, name, k, cols, nids = ent
+                    key, src, i, lab, name, k, cols, nids, ntail = ent
                     item = np.dtype(name).itemsize
+                    in_tail = ntail > 0 and a >= k - ntail
                     if src == rank and dst == rank:
                         _, _, table, idx = mine[i]
-                        part = DevTable(table.raw[a:b_], table.width) if hasattr(table, "raw") else table[a:b_]
+                        part = table.rows(a, b_) if hasattr(table, "raw") else table[a:b_]
                         got[(b, pos)] = (key, name, part, idx if first else None, a, b_)
                     elif src == rank:
                         _, _, table, idx = mine[i]
-                        rows = table.raw[a:b_] if hasattr(table, "raw") else np.ascontiguousarray(table[a:b_])
-                        parts = [self._wire(DevTable(rows, table.width) if hasattr(table, "raw") else rows)]
+                        parts = self._wire_table(table.rows(a, b_) if hasattr(table, "raw") else np.ascontiguousarray(table[a:b_]))
                         if first:
                             parts += [self._wire(idx.counts.astype(np.int64)), self._wire(idx.flat.astype(np.int64))]
                         for t in parts:
                             if t.numel():
                                 ops.append(dist.P2POp(dist.isend, t, dst))
                                 self.bytes_sent += int(t.numel())
-                        got.setdefault("_keep", []).append(parts)  # (alive until the step's requests are done)
+                        keep.append(parts)
                     elif dst == rank:
-                        tb = torch.empty((b_ - a, cols * item), dtype=torch.uint8, device=self.tdev)
+                        tb = torch.empty((b_ - a, (cols - 1) // 8 if in_tail else cols * item), dtype=torch.uint8, device=self.tdev)
                         bufs = [tb]
                         if first:
                             bufs += [torch.empty(k * 8, dtype=torch.uint8, device=self.tdev),
@@ -483,26 +489,30 @@ class _Exchange:
                                 ops.append(dist.P2POp(dist.irecv, t.reshape(-1), src))
                                 self.bytes_received += int(t.numel())
                         got[(b, pos)] = (key, name, bufs, None, a, b_)
+                        cols_of[(b, pos)] = cols if in_tail else 0
             reqs = dist.batch_isend_irecv(ops) if ops else []
-            return reqs, got
+            return reqs, got, (keep, dict(cols_of))
 
-        def finish(reqs: list, got: dict) -> dict[int, list[tuple[tp.Any, _IndexLists]]]:
+        def finish(reqs: list, got: dict, keep_cols: tuple) -> dict[int, list[tuple[tp.Any, _IndexLists]]]:
+            keep, recv_cols = keep_cols
             for req in reqs:
                 req.wait()
+            del keep
             if reqs and self.tdev.type == "cuda":
                 torch.cuda.synchronize()
             per_batch: dict[int, list[tuple[int, tuple[tp.Any, _IndexLists]]]] = {}
-            for kpos, val in got.items():
-                if kpos == "_keep":
-                    continue
-                b, pos = kpos
+            for (b, pos), val in got.items():
                 key, name, payload, idx_full, a, b_ = val
                 if isinstance(payload, list):  # received
                     tb = payload[0]
                     if len(payload) == 3:
                         idx_full = _IndexLists(payload[1].cpu().numpy().view(np.int64).copy(), payload[2].cpu().numpy().view(np.int64).copy())
                     if self.table_dev is not None:
-                        part = DevTable(tb if tb.device == self.table_dev else tb.to(self.table_dev), np.dtype(name).itemsize)
+                        tb = tb if tb.device == self.table_dev else tb.to(self.table_dev)
+                        if recv_cols.get((b, pos), 0):  # a chunk of a packed singleton tail
+                            part = DevTable(torch.empty((0, recv_cols[(b, pos)]), dtype=torch.uint8, device=tb.device), 1, tb)
+                        else:
+                            part = DevTable(tb, np.dtype(name).itemsize)
                     else:
                         part = tb.numpy().view(np.dtype(name)).reshape(b_ - a, -1)
                 else:
@@ -512,13 +522,15 @@ class _Exchange:
                     offsets[(b, key)] = np.concatenate(([0], np.cumsum(idx_full.counts)))
                 full, off = members[(b, key)], offsets[(b, key)]
                 sub = _IndexLists(full.counts[a:b_], full.flat[int(off[a]):int(off[b_])])
+                if b_ >= len(full.counts):  # the table's last chunk: its member lists are not needed any more
+                    del members[(b, key)], offsets[(b, key)]
                 per_batch.setdefault(b, []).append((pos, (part, sub)))
             return {b: [e for _, e in sorted(v, key=lambda pe: pe[0])] for b, v in per_batch.items()}
 
-        pending = post(0) if n_steps else ([], {})
+        pending = post(0) if n_steps else ([], {}, ([], {}))
         for step in range(n_steps):
             ready = finish(*pending)
-            pending = post(step + 1) if step + 1 < n_steps else ([], {})  # the next slab travels while this one is inserted
+            pending = post(step + 1) if step + 1 < n_steps else ([], {}, ([], {}))  # the next slab travels while this one is inserted
             live = [b for b in owned if b in ready]
             if live:
                 fit_buffers_concurrently([trees[b] for b in live], [ready[b] for b in live])
@@ -540,40 +552,45 @@ class _Exchange:
         chunks = self._plan(mine, bin_size)  # 1. descriptors, 2. batches and their owners
         # 3. payloads
         ops, recv_into = [], {}
+        keep_alive: list = []  # send buffers, until the requests are done
         mine_out: dict[int, list[tp.Any]] = {}
         for b, chunk in enumerate(chunks):
             dst = owner(b)
-            for pos, (_, src, i, lab, name, k, cols, nids) in enumerate(chunk):
+            for pos, (_, src, i, lab, name, k, cols, nids, ntail) in enumerate(chunk):
                 item = np.dtype(name).itemsize
                 if src == rank and dst == rank:
                     mine_out.setdefault(b, []).append((pos, mine[i]))
                 elif src == rank:
                     _, _, table, idx = mine[i]
-                    parts = [self._wire(table), self._wire(idx.counts.astype(np.int64)), self._wire(idx.flat.astype(np.int64))]
+                    parts = self._wire_table(table) + [self._wire(idx.counts.astype(np.int64)), self._wire(idx.flat.astype(np.int64))]
+                    keep_alive.append(parts)
                     for t in parts:
                         if t.numel():
                             ops.append(dist.P2POp(dist.isend, t, dst))
                             self.bytes_sent += int(t.numel())
                 elif dst == rank:
-                    tb = torch.empty((k, cols * item), dtype=torch.uint8, device=self.tdev)
+                    tb = torch.empty((k - ntail, cols * item), dtype=torch.uint8, device=self.tdev)
+                    tt = torch.empty((ntail, (cols - 1) // 8), dtype=torch.uint8, device=self.tdev)  # the packed singleton tail
                     cb = torch.empty(k * 8, dtype=torch.uint8, device=self.tdev)
                     ib = torch.empty(nids * 8, dtype=torch.uint8, device=self.tdev)
-                    for t in (tb, cb, ib):
+                    for t in (tb, tt, cb, ib):
                         if t.numel():
                             ops.append(dist.P2POp(dist.irecv, t.reshape(-1), src))
                             self.bytes_received += int(t.numel())
-                    recv_into[(b, pos)] = (lab, name, tb, cb, ib, k, cols)
+                    recv_into[(b, pos)] = (lab, name, (tb, tt), cb, ib, k, cols)
         if ops:
             for req in dist.batch_isend_irecv(ops):
                 req.wait()
             if on_dev:
                 torch.cuda.synchronize()
-        for (b, pos), (lab, name, tb, cb, ib, k, cols) in recv_into.items():
+        del keep_alive
+        for (b, pos), (lab, name, (tb, tt), cb, ib, k, cols) in recv_into.items():
             cnt_np = cb.cpu().numpy().view(np.int64).copy()
             ids_np = ib.cpu().numpy().view(np.int64).copy()
             table: tp.Any
             if self.table_dev is not None:  # stays a tensor end to end (gloo cannot carry device tensors: staged)
-                table = DevTable(tb if tb.device == self.table_dev else tb.to(self.table_dev), np.dtype(name).itemsize)
+                table = DevTable(tb if tb.device == self.table_dev else tb.to(self.table_dev), np.dtype(name).itemsize,
+                                 tt if tt.device == self.table_dev else tt.to(self.table_dev))
             else:
                 table = tb.numpy().view(np.dtype(name)).reshape(k, cols)
             mine_out.setdefault(b, []).append((pos, (lab, name, table, _IndexLists(cnt_np, ids_np))))

@@ -187,6 +187,13 @@ int bbh_tree_export_leaves(bbh_tree* t, uint32_t* leaf_ids, uint64_t* n_samples,
 int bbh_tree_gather_buffers(bbh_tree* t, const int64_t* positions, int64_t m,
                             int32_t width, void* out);
 
+/* Packed centroids (np.packbits order, ceil(F/8) bytes each) of the leaves at `positions`
+ * (chain order; host int64): BitBirch.get_centroids on a selection (bitbirch.py:895-907).
+ * For a leaf BitFeature of one fingerprint this IS its buffer row in packed form, which is
+ * how multiround keeps the singleton tail of a uint8 round table (multiround.py:132-143:
+ * 2049 bytes per row there) at 256 bytes per row in HBM.  out: m x ceil(F/8), host or device. */
+int bbh_tree_gather_centroids(bbh_tree* t, const int64_t* positions, int64_t m, uint8_t* out);
+
 /* counters for tests / profiling: [0] similarity calls, [1] rows compared, [2] merges,
  * [3] appends, [4] splits, [5] nodes, [6] max depth, [7] BitFeature slots used */
 int bbh_tree_stats(bbh_tree* t, uint64_t* out8);

@@ -3,7 +3,7 @@
 Tanimoto kernel on rows in pinned host memory (the PCIe-inclusive rate - never the bench's `value`).
     python tools/ingest.py [rows]"""
 import os, sys, time, tempfile
-os.environ.setdefault("BBHIP_LAUNCH_LOG", "0")
+os.environ.pop("BBHIP_LAUNCH_LOG", None)  # (any value, "0" included, turns the log on)
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
 import numpy as np
 import torch

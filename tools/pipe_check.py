@@ -1,7 +1,7 @@
 """HIP engine (pipelined kernel by default) against the CPU oracle, element by element, on the bench workloads.
     python tools/pipe_check.py [rows] [bf ...]"""
 import os, sys, time
-os.environ.setdefault("BBHIP_LAUNCH_LOG", "0")
+os.environ.pop("BBHIP_LAUNCH_LOG", None)  # (any value, "0" included, turns the log on)
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
 import numpy as np
 import torch
