@@ -367,6 +367,13 @@ class HipEngine:
         _lib.check(self._lib.bbh_tree_stats(self._h, out.ctypes.data))
         return out
 
+    def kernel_counts(self) -> NDArray[np.uint64]:
+        r"""[0..2] elements inserted by the pipelined / steady-state / complete kernel, [3..5] their launches, [6] launches
+        that ended with "tree shape not handled by the pipeline", [7] launches that ended on an exhausted pool."""
+        out = np.zeros(8, dtype=np.uint64)
+        _lib.check(self._lib.bbh_tree_kernel_counts(self._h, out.ctypes.data))
+        return out
+
     def close(self) -> None:
         if getattr(self, "_h", None) is not None and self._h.value:
             self._lib.bbh_tree_destroy(self._h)

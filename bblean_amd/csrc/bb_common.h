@@ -138,6 +138,7 @@ struct ProfRec {
 extern bool g_prof_on;
 void prof_begin(const char* name, hipStream_t s, size_t* token);
 void prof_units(size_t token, long long units);
+void prof_rename(size_t token, const char* name);  // ("tree_insert/pipe": also counted under "tree_insert")
 void prof_end(size_t token, hipStream_t s);
 
 struct ProfScope {

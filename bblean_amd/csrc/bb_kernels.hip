@@ -30,6 +30,17 @@ void prof_begin(const char* name, hipStream_t s, size_t* token) {
     *token = g_prof.size() - 1;
 }
 
+void prof_rename(size_t token, const char* name) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (token < g_prof.size()) g_prof[token].name = name;
+}
+
+// a record named "tree_insert/pipe" answers to "tree_insert/pipe" and to "tree_insert"
+static bool prof_match(const std::string& rec, const char* query) {
+    const size_t n = std::strlen(query);
+    return rec.compare(0, n, query) == 0 && (rec.size() == n || rec[n] == '/');
+}
+
 void prof_units(size_t token, long long units) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     if (token < g_prof.size()) g_prof[token].units += units;
@@ -933,7 +944,7 @@ extern "C" int bbh_profile_units(const char* name, int64_t* units) {
     std::lock_guard<std::mutex> lk(bb::g_prof_mu);
     int64_t u = 0;
     for (auto& r : bb::g_prof)
-        if (r.name == name) u += r.units;
+        if (bb::prof_match(r.name, name)) u += r.units;
     if (units) *units = u;
     return BBH_OK;
 }
@@ -943,7 +954,7 @@ extern "C" int bbh_profile_get(const char* name, int64_t* launches, double* tota
     int64_t cnt = 0;
     double ms = 0.0;
     for (auto& r : bb::g_prof) {
-        if (r.name != name) continue;
+        if (!bb::prof_match(r.name, name)) continue;
         if (hipEventSynchronize(r.b) != hipSuccess) continue;
         float t = 0.f;
         if (hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) {

@@ -2100,15 +2100,17 @@ static const FastKernel kFastKernels[] = {  // (most specific first)
 
 // the pipelined kernel (bb_tree_pipe.inc): packed fingerprints, one tree per launch, diameter / tolerance-diameter
 struct PipeKernel {
-    int bf, crit;
+    int bf, crit, ml;  // ml: the multi-level instance (several exact internal levels, pipe_router_ml)
     void (*fn)(TreeDev*);
     uint32_t lds;
 };
 static const PipeKernel kPipeKernels[] = {
-    {50, BBH_CRIT_DIAMETER, k_tree_pipe<KP<50, BBH_CRIT_DIAMETER>>, pipe_layout(50).total},
-    {50, BBH_CRIT_TOL_DIAMETER, k_tree_pipe<KP<50, BBH_CRIT_TOL_DIAMETER>>, pipe_layout(50).total},
-    {254, BBH_CRIT_DIAMETER, k_tree_pipe<KP<254, BBH_CRIT_DIAMETER>>, pipe_layout(254).total},
-    {254, BBH_CRIT_TOL_DIAMETER, k_tree_pipe<KP<254, BBH_CRIT_TOL_DIAMETER>>, pipe_layout(254).total},
+    {50, BBH_CRIT_DIAMETER, 0, k_tree_pipe<KP<50, BBH_CRIT_DIAMETER>>, pipe_layout(50).total},
+    {50, BBH_CRIT_TOL_DIAMETER, 0, k_tree_pipe<KP<50, BBH_CRIT_TOL_DIAMETER>>, pipe_layout(50).total},
+    {254, BBH_CRIT_DIAMETER, 0, k_tree_pipe<KP<254, BBH_CRIT_DIAMETER>>, pipe_layout(254).total},
+    {254, BBH_CRIT_TOL_DIAMETER, 0, k_tree_pipe<KP<254, BBH_CRIT_TOL_DIAMETER>>, pipe_layout(254).total},
+    {50, BBH_CRIT_DIAMETER, 1, k_tree_pipe<KP<50, BBH_CRIT_DIAMETER, 1>>, pipe_layout(50, 1).total},
+    {50, BBH_CRIT_TOL_DIAMETER, 1, k_tree_pipe<KP<50, BBH_CRIT_TOL_DIAMETER, 1>>, pipe_layout(50, 1).total},
 };
 
 // uint8 BitFeature buffers with n_samples == 1 are plain fingerprints in unpacked form (ls in {0, 1}):
@@ -2329,6 +2331,10 @@ struct bbh_tree {
     uint32_t *d_chain_nodes = nullptr, *d_chain_rows = nullptr;
     size_t d_chain_cap = 0;
     int64_t unsup_stretch = 0;  // elements the steady-state kernel took after the pipelined one last refused the tree's shape
+    // which kernel inserted what (bbh_tree_kernel_counts): elements and launches by {pipelined, steady-state, complete}, then
+    // the launches the pipelined kernel ended with STOP_PIPE_UNSUPPORTED and the pool-exhaustion stops (STOP_NODES / STOP_CF*)
+    uint64_t kcount[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    bool pipe_ml = false;  // the pipelined kernel asked for its multi-level instance (informative levels above the leaf-parents)
 };
 
 namespace {
@@ -2346,9 +2352,9 @@ int grow_pool(T*& p, size_t used_elems, size_t new_elems) {
 
 // BBHIP_TINY_POOLS=1 (tests): pools are pre-grown by next to nothing, so that the kernels run out of nodes / cluster-feature
 // slots in the middle of their runs and every STOP_* -> grow -> relaunch path is exercised
-static bool tiny_pools() {
-    static const bool on = [] { const char* v = getenv("BBHIP_TINY_POOLS"); return v != nullptr && v[0] != '\0' && std::strcmp(v, "0") != 0; }();
-    return on;
+static bool tiny_pools() {  // (read on every call: tests switch it on and off inside one process)
+    const char* v = getenv("BBHIP_TINY_POOLS");
+    return v != nullptr && v[0] != '\0' && std::strcmp(v, "0") != 0;
 }
 // a pool that has to grow grows by at least half (a tree fed in 64 MiB slabs asked for a slightly larger pool with every
 // slab, i.e. copied all of it every time); `hint` is what the caller expects to need
@@ -2431,6 +2437,8 @@ int init_empty(bbh_tree* t) {
     std::memset(h.sphase, 0, sizeof(h.sphase));
     h.stats[5] = 1;
     t->chain_valid = false;
+    t->pipe_ml = false;
+    t->unsup_stretch = 0;
     return BBH_OK;
 }
 
@@ -2490,6 +2498,7 @@ int configure(bbh_tree* t, int32_t bf, int32_t n_features) {
                 for (const PipeKernel& pk : kPipeKernels)
                     BB_HIP(hipFuncSetAttribute((const void*)pk.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pk.lds));
                 BB_HIP(hipFuncSetAttribute((const void*)k_tree_pipe<KP<50, BBH_CRIT_DIAMETER>, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pipe_layout(50).total));
+                BB_HIP(hipFuncSetAttribute((const void*)k_tree_pipe<KP<50, BBH_CRIT_DIAMETER, 1>, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pipe_layout(50, 1).total));
                 BB_HIP(hipFuncSetAttribute((const void*)k_tree_pipe<KP<254, BBH_CRIT_DIAMETER>, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pipe_layout(254).total));
             } else {
                 return bb::fail(BBH_ERR_NO_DEVICE, "device %d offers %d bytes of LDS per workgroup, the tree kernels need %u", t->device, cap,
@@ -2639,8 +2648,9 @@ int run_insert_multi(std::vector<Job>& jobs, hipStream_t s) {
             const PipeKernel* pk = nullptr;
             if (fk != nullptr && !no_pipe && !prof_phases && single && f_packed && jobs[active[0]].old_left == 0 &&
                 harr[0].n_elems < (1ll << 31)) {
+                const int want_ml = jobs[active[0]].t->pipe_ml ? 1 : 0;
                 for (const PipeKernel& c : kPipeKernels)
-                    if (pk == nullptr && c.bf == (all50 ? 50 : 254) && c.crit == f_crit) pk = &c;
+                    if (pk == nullptr && c.bf == (all50 ? 50 : 254) && c.crit == f_crit && c.ml == want_ml) pk = &c;
             }
             if (pk != nullptr) {
                 // tier promotions of elements in flight take cf16 / cf32 slots without asking: keep a reserve
@@ -2662,7 +2672,9 @@ int run_insert_multi(std::vector<Job>& jobs, hipStream_t s) {
                 }
                 log_kernel = "pipe";
                 static const bool pipe_phases = getenv("BBHIP_PIPE_PHASES") != nullptr;
-                if (pipe_phases && pk->crit == BBH_CRIT_DIAMETER && pk->bf == 50)
+                if (pipe_phases && pk->crit == BBH_CRIT_DIAMETER && pk->bf == 50 && pk->ml)
+                    hipLaunchKernelGGL((k_tree_pipe<KP<50, BBH_CRIT_DIAMETER, 1>, true>), grid, block, pk->lds, s, dptr);
+                else if (pipe_phases && pk->crit == BBH_CRIT_DIAMETER && pk->bf == 50)
                     hipLaunchKernelGGL((k_tree_pipe<KP<50, BBH_CRIT_DIAMETER>, true>), grid, block, pk->lds, s, dptr);
                 else if (pipe_phases && pk->crit == BBH_CRIT_DIAMETER)
                     hipLaunchKernelGGL((k_tree_pipe<KP<254, BBH_CRIT_DIAMETER>, true>), grid, block, pk->lds, s, dptr);
@@ -2687,6 +2699,8 @@ int run_insert_multi(std::vector<Job>& jobs, hipStream_t s) {
             }
             e = hipGetLastError();
         }
+        if (prof_tok != (size_t)-1)
+            bb::prof_rename(prof_tok, log_kernel[0] == 'p' ? "tree_insert/pipe" : (log_kernel[0] == 'f' ? "tree_insert/fast" : "tree_insert/complete"));
         if (e == hipSuccess) e = hipMemcpyAsync(harr.data(), dptr, active.size() * sizeof(TreeDev), hipMemcpyDeviceToHost, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);
         if (e != hipSuccess) { rc = bb::fail(BBH_ERR_HIP, "tree_insert: %s", hipGetErrorString(e)); break; }
@@ -2716,25 +2730,31 @@ int run_insert_multi(std::vector<Job>& jobs, hipStream_t s) {
             std::memcpy(h.phase, back.phase, sizeof(h.phase));
             std::memcpy(h.sphase, back.sphase, sizeof(h.sphase));
             j.done += back.processed;
+            {
+                const int kk = log_kernel[0] == 'p' ? 0 : (log_kernel[0] == 'f' ? 1 : 2);
+                t->kcount[kk] += (uint64_t)back.processed;
+                t->kcount[3 + kk] += 1;
+                if (back.stop_reason == STOP_PIPE_UNSUPPORTED) t->kcount[6] += 1;
+                if (back.stop_reason == STOP_NODES || back.stop_reason == STOP_CF8 || back.stop_reason == STOP_CF16 || back.stop_reason == STOP_CF32) t->kcount[7] += 1;
+            }
             if (j.old_left > 0) j.old_left = std::max<int64_t>(0, j.old_left - back.processed);
             if (prof_tok != (size_t)-1) bb::prof_units(prof_tok, back.processed);  // elements this launch inserted
-            j.stalls = (back.processed == 0 && back.stop_reason != STOP_PIPE_UNSUPPORTED) ? j.stalls + 1 : 0;
+            j.stalls = (back.processed == 0 && back.stop_reason != STOP_PIPE_UNSUPPORTED && back.stop_reason != STOP_PIPE_NEEDS_ML) ? j.stalls + 1 : 0;
             if (j.stalls > 3) { rc = bb::fail(BBH_ERR_CAPACITY, "tree engine made no progress (stop reason %d)", back.stop_reason); break; }
             const int64_t left = j.n - j.done;
-            auto more = [&](uint32_t used, uint32_t cap, int64_t per_elem_hint) -> uint32_t {
+            // what a pool that ran out is grown to: half as much again, or what the elements that are left are expected to
+            // need (pregrow's rates) if that is more
+            auto more = [&](uint32_t used, uint32_t cap, uint64_t expect) -> uint32_t {
                 if (tiny_pools()) return clamp30((uint64_t)cap + 8 + 2 * (uint64_t)h.ctr[C_DEPTH]);  // (one insertion's worst case fits)
-                uint64_t want = (uint64_t)cap + cap / 2;  // (grow_target's minimum; a pool of tens of GB is not doubled)
-                uint64_t est = (uint64_t)used + (uint64_t)(left * per_elem_hint) / 4 + 4096;
-                if (est > want) want = est;
-                if (want > 0x3FFFFFFFull) want = 0x3FFFFFFFull;
-                return (uint32_t)want;
+                return clamp30(std::max<uint64_t>((uint64_t)cap + cap / 2, (uint64_t)used + expect));
             };
+            const uint64_t uleft = (uint64_t)std::max<int64_t>(left, 0);
             switch (back.stop_reason) {
                 case STOP_DONE: break;
-                case STOP_NODES: rc = grow_nodes(t, more(h.ctr[C_NODES], h.cap_nodes, 1)); break;
-                case STOP_CF8: rc = grow_cf(t, 0, more(h.ctr[C_N8], h.cap8, 1)); break;
-                case STOP_CF16: rc = grow_cf(t, 1, more(h.ctr[C_N16], h.cap16, 1)); break;
-                case STOP_CF32: rc = grow_cf(t, 2, more(h.ctr[C_N32], h.cap32, 1)); break;
+                case STOP_NODES: rc = grow_nodes(t, more(h.ctr[C_NODES], h.cap_nodes, uleft / (uint64_t)std::max(1, h.bf / 2) + 64)); break;
+                case STOP_CF8: rc = grow_cf(t, 0, more(h.ctr[C_N8], h.cap8, uleft / 8 + 1024)); break;
+                case STOP_CF16: rc = grow_cf(t, 1, more(h.ctr[C_N16], h.cap16, (j.width == 2 ? uleft : uleft / 64) + 64)); break;
+                case STOP_CF32: rc = grow_cf(t, 2, more(h.ctr[C_N32], h.cap32, uleft / (uint64_t)std::max(1, h.bf / 6) + 256)); break;
                 case STOP_DEPTH: rc = bb::fail(BBH_ERR_CAPACITY, "tree deeper than %d levels (or corrupt link)", MAXD); break;
                 case STOP_RANGE: rc = bb::fail(BBH_ERR_INVALID, "n_samples exceeds 2^32-1 (engine limit)"); break;
                 case STOP_PIPE_UNSUPPORTED:
@@ -2744,6 +2764,7 @@ int run_insert_multi(std::vector<Job>& jobs, hipStream_t s) {
                     t->unsup_stretch = back.processed > 0 || t->unsup_stretch == 0 ? 8192 : std::min<int64_t>(t->unsup_stretch * 2, 1ll << 22);
                     j.old_left = t->unsup_stretch;
                     break;
+                case STOP_PIPE_NEEDS_ML: t->pipe_ml = true; break;  // relaunched at once, with the multi-level instance
                 case STOP_INTERNAL: rc = bb::fail(BBH_ERR_HIP, "pipelined kernel: a wait gave up (internal error)"); break;
                 default: rc = bb::fail(BBH_ERR_HIP, "unknown stop reason %d", back.stop_reason); break;
             }
@@ -3217,6 +3238,12 @@ extern "C" int bbh_tree_gather_centroids(bbh_tree* t, const int64_t* positions, 
     if (!t || (m > 0 && (!positions || !out))) return bb::fail(BBH_ERR_INVALID, "null argument");
     if (m == 0) return BBH_OK;
     return gather_positions(t, positions, m, 0, nullptr, out);
+}
+
+extern "C" int bbh_tree_kernel_counts(bbh_tree* t, uint64_t* out8) {
+    if (!t || !out8) return bb::fail(BBH_ERR_INVALID, "null argument");
+    for (int i = 0; i < 8; ++i) out8[i] = t->kcount[i];
+    return BBH_OK;
 }
 
 extern "C" int bbh_tree_stats(bbh_tree* t, uint64_t* out8) {

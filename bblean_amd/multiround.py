@@ -94,6 +94,19 @@ def _files_range_tuples(files: tp.Sequence[tp.Any]) -> list[tuple[str, tp.Any, i
 Tables = tuple[dict[str, NDArray[np.integer]], dict[str, _IndexLists]]
 
 
+def _release_cached_hbm() -> None:
+    r"""Between rounds: HBM that torch's allocator keeps cached after the tables of a round were freed goes back to the
+    driver (the tree pools come from the library's own allocator, which cannot use it; at 100 M rows the two caches together
+    decide whether the final tree fits next to the last round's tables)."""
+    try:
+        import torch
+
+        if torch.cuda.is_available():
+            torch.cuda.empty_cache()
+    except Exception:  # pragma: no cover - nothing to release without torch / a device
+        pass
+
+
 # host/device bytes of raw input handed to one concurrent launch group
 _GROUP_BYTES = 24 << 30
 
@@ -143,6 +156,8 @@ def _initial_rounds(
                 t.delete_internal_nodes()
             tabs = [t._bf_tables(t._leaf_order(True), device=device_tables) for t in trees]
         out.extend(tabs)
+        del trees, tabs
+        _release_cached_hbm()
     return out
 
 
@@ -705,6 +720,7 @@ def run_multiround_distributed(
             for name in bufs:
                 mine.append((str(b).zfill(z), name, bufs[name], mols[name]))
         del trees
+        _release_cached_hbm()
         timer.end_timing(f"round-{round_idx}")
 
     round_idx += 1

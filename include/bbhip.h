@@ -198,9 +198,16 @@ int bbh_tree_gather_centroids(bbh_tree* t, const int64_t* positions, int64_t m, 
  * [3] appends, [4] splits, [5] nodes, [6] max depth, [7] BitFeature slots used */
 int bbh_tree_stats(bbh_tree* t, uint64_t* out8);
 
+/* Which of the three insertion kernels did the work, since the handle was created (tests, bench.py):
+ * [0..2] elements inserted by the pipelined / the steady-state / the complete kernel, [3..5] their launches,
+ * [6] launches the pipelined kernel ended because the tree had a shape it does not handle, [7] launches that
+ * ended because a pool was exhausted (the host grew it and relaunched). */
+int bbh_tree_kernel_counts(bbh_tree* t, uint64_t* out8);
+
 /* Per-kernel timing with HIP events on the stream each kernel is launched on.
  * bbh_profile_enable(1) turns it on; bbh_profile_get returns launches and summed
- * milliseconds for the kernel called `name` ("jt_arr_vec", "tree_insert", ...). */
+ * milliseconds for the kernel called `name` ("jt_arr_vec", "tree_insert", ...; the tree kernels are recorded as
+ * "tree_insert/pipe", "tree_insert/fast" and "tree_insert/complete", "tree_insert" is their sum). */
 int bbh_profile_enable(int on);
 int bbh_profile_reset(void);
 int bbh_profile_get(const char* name, int64_t* launches, double* total_ms);

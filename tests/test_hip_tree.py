@@ -317,3 +317,41 @@ def test_hip_streaming_ingest_from_file(tmp_path, monkeypatch):
     hip.refine_inplace([f1, f2], n_largest=2)  # re-inserts ~12 k BitFeature buffers from host tables
     ora.refine_inplace([f1, f2], n_largest=2)
     _same(hip, ora)
+
+
+@pytest.mark.parametrize("kind,bf,n,thr", [
+    ("hier", 50, 120_000, 0.6), ("dense", 50, 80_000, 0.6), ("rdkit", 50, 120_000, 0.6),
+    ("hier", 254, 120_000, 0.6), ("dense", 254, 80_000, 0.6),
+    ("hier", 50, 60_000, 0.35),
+])
+def test_hip_pipelined_kernel_informative_internal_levels_vs_oracle(kind, bf, n, thr):
+    r"""Trees whose INTERNAL levels stay informative: planted dense prototypes / two-level families (tests/golden/cases.py
+    clustered_dense, clustered_hier: the generators that exist because their upper centroids are not all-zero) and
+    S-rdkit-like rows.  Every level above the leaves compares (bitbirch.py:317-320) and every tracking row on the path takes
+    the element and a new majority centroid (:352-357) - at bf 50 through the multi-level router of the pipelined kernel
+    (pipe_router_ml: centroid drift at the leaf-parent AND above it while elements are in flight: the `dense` prototypes sit
+    at 45-60 % density, so a tracking row's features hover around the majority threshold and its centroid changes with almost
+    every element, two levels up as well), at bf 254 through whatever the host picks for the shape.  Element by element the
+    oracle's leaf ids, chunk by chunk its counters; at the end clusters, centroids and BitFeature tables."""
+    from cases import clustered_dense, clustered_hier, dense_rdkit_like
+
+    if kind == "hier":
+        fps = clustered_hier(n, 2048, 12, n // 50, 7)
+    elif kind == "dense":
+        fps = clustered_dense(n, 2048, n // 50, 7)
+    else:
+        fps = dense_rdkit_like(n, 2048, 2026)
+    kw = dict(branching_factor=bf, threshold=thr, merge_criterion="diameter")
+    hip, ora = BitBirch(**kw), BitBirch(_engine_factory=OracleEngine, **kw)
+    for lo in range(0, n, 20_000):
+        hip.fit(fps[lo:lo + 20_000])
+        ora.fit(fps[lo:lo + 20_000])
+        bad = np.nonzero(hip._log_leaf[-1] != ora._log_leaf[-1])[0]
+        assert bad.size == 0, f"first differing element {lo + int(bad[0])}"
+        assert hip._engine.stats()[:7].tolist() == ora._engine.stats()[:7].tolist(), lo
+    _same(hip, ora)
+    kc = hip._engine.kernel_counts()
+    assert int(kc[:3].sum()) == n
+    if bf == 50:
+        # the pipelined kernel took the tree once it had a root above the leaves, several exact levels or not
+        assert int(kc[0]) > n // 2, kc.tolist()
