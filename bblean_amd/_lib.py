@@ -65,6 +65,7 @@ _PROTOTYPES = {
     "bbh_profile_reset": (_int, []),
     "bbh_profile_get": (_int, [C.c_char_p, C.POINTER(_i64), C.POINTER(_f64)]),
     "bbh_profile_units": (_int, [C.c_char_p, C.POINTER(_i64)]),
+    "bbh_profile_longest": (_int, [C.c_char_p, C.POINTER(_f64), C.POINTER(_i64)]),
 }
 
 EXPORTED_SYMBOLS = tuple(_PROTOTYPES)

@@ -442,9 +442,10 @@ class BitBirch:
             bad = np.nonzero(counts != n_col)[0]
             if bad.size:
                 i = int(bad[0])
+                where = f" (buffer {i} of {k}" + (f", device table: {bufs.n_head} rows + {bufs.n_tail} packed)" if is_dev else ")")
                 raise ValueError(
                     "Expected len(mol_indices) == buffer[-1],"
-                    f" but found {int(counts[i])} != {int(n_col[i])}"
+                    f" but found {int(counts[i])} != {int(n_col[i])}" + where
                 )
         self._is_init = True
         if not k:
@@ -811,7 +812,8 @@ class BitBirch:
         (reference bitbirch.py:1187-1214)."""
         self._require_init()
         self.delete_internal_nodes()
-        bufs, mols = self._refine_tables(X, initial_mol, input_is_packed, n_largest)
+        # (the tables stay in HBM when the engine can do that: gathered there, re-inserted from there)
+        bufs, mols = self._refine_tables(X, initial_mol, input_is_packed, n_largest, device=True)
         self.reset()
         for name in bufs:
             self._fit_buffers(bufs[name], reinsert_index_seqs=mols[name])
@@ -845,7 +847,7 @@ class BitBirch:
                 random.seed(seed)
                 random.shuffle(perm)
                 order = order[np.asarray(perm, dtype=np.int64)]
-            bufs, mols = self._bf_tables(order)
+            bufs, mols = self._bf_tables(order, device=True)
             self.reset()
             self.threshold += extra_threshold
             for name in bufs:

@@ -949,6 +949,24 @@ extern "C" int bbh_profile_units(const char* name, int64_t* units) {
     return BBH_OK;
 }
 
+extern "C" int bbh_profile_longest(const char* name, double* ms_out, int64_t* units_out) {
+    std::lock_guard<std::mutex> lk(bb::g_prof_mu);
+    double best = -1.0;
+    int64_t u = 0;
+    for (auto& r : bb::g_prof) {
+        if (!bb::prof_match(r.name, name)) continue;
+        if (hipEventSynchronize(r.b) != hipSuccess) continue;
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, r.a, r.b) == hipSuccess && (double)t > best) {
+            best = t;
+            u = r.units;
+        }
+    }
+    if (ms_out) *ms_out = best < 0.0 ? 0.0 : best;
+    if (units_out) *units_out = u;
+    return BBH_OK;
+}
+
 extern "C" int bbh_profile_get(const char* name, int64_t* launches, double* total_ms) {
     std::lock_guard<std::mutex> lk(bb::g_prof_mu);
     int64_t cnt = 0;

@@ -115,6 +115,7 @@ struct TreeDev {
     unsigned long long stats[8];
     unsigned long long phase[16];  // shader-clock cycles per phase (thread 0), debug; [8..] descent detail
     unsigned long long sphase[8]; // same, inside split_node
+    unsigned long long mlprof[4];  // multi-level router (phase-timer build): tracking-CF cache misses, levels committed
     // job of the next launch
     const uint8_t* rows;
     long long row_stride;
@@ -2435,6 +2436,7 @@ int init_empty(bbh_tree* t) {
     std::memset(h.stats, 0, sizeof(h.stats));
     std::memset(h.phase, 0, sizeof(h.phase));
     std::memset(h.sphase, 0, sizeof(h.sphase));
+    std::memset(h.mlprof, 0, sizeof(h.mlprof));
     h.stats[5] = 1;
     t->chain_valid = false;
     t->pipe_ml = false;
@@ -2729,6 +2731,7 @@ int run_insert_multi(std::vector<Job>& jobs, hipStream_t s) {
             std::memcpy(h.stats, back.stats, sizeof(h.stats));
             std::memcpy(h.phase, back.phase, sizeof(h.phase));
             std::memcpy(h.sphase, back.sphase, sizeof(h.sphase));
+            std::memcpy(h.mlprof, back.mlprof, sizeof(h.mlprof));
             j.done += back.processed;
             {
                 const int kk = log_kernel[0] == 'p' ? 0 : (log_kernel[0] == 'f' ? 1 : 2);
@@ -3262,6 +3265,11 @@ extern "C" int bbh_tree_stats(bbh_tree* t, uint64_t* out8) {
             fprintf(stderr, " %s: %.3f/insert x %.0f cycles", kd[i], n > 0 ? (double)t->h.sphase[2 * i + 1] / n : 0.0,
                     t->h.sphase[2 * i + 1] ? (double)t->h.sphase[2 * i] / (double)t->h.sphase[2 * i + 1] : 0.0);
         fprintf(stderr, "\n");
+        if (t->pipe_ml)
+            fprintf(stderr, "[bbhip pipe multi-level router] upper-slot fills %.3f/insert x %.0f cycles; tracking levels committed %.3f/insert, "
+                    "cluster-feature cache misses %.3f/insert\n", n > 0 ? (double)t->h.sphase[7] / n : 0.0,
+                    t->h.sphase[7] ? (double)t->h.sphase[6] / (double)t->h.sphase[7] : 0.0, n > 0 ? (double)t->h.mlprof[1] / n : 0.0,
+                    n > 0 ? (double)t->h.mlprof[0] / n : 0.0);
     }
     if (getenv("BBHIP_PHASES")) {
         fprintf(stderr, "[bbhip phases, cycles/insert]");

@@ -108,11 +108,32 @@ def synth_rdkit_like(n: int, seed: int, device, n_features: int = 2048):
     return _synth_planted(n, seed, device, 900.0, 250.0, 64, 1900, 0.12, n_features)
 
 
+def synth_hier(n: int, seed: int, device, n_features: int = 2048):
+    r"""Two-level planted families (tests/golden/cases.py clustered_hier, on the GPU): 12 super-prototypes at 50 % density,
+    n/50 cluster prototypes (a super-prototype with 12 % of its bits toggled), rows = a cluster prototype with 4 % toggled.
+    The tracking centroids of the INTERNAL tree levels stay informative: every level compares and routes for real."""
+    import torch
+
+    g = torch.Generator(device=device).manual_seed(seed)
+    k = max(n // 50, 1)
+    sup = torch.rand((12, n_features), device=device, generator=g) < 0.5
+    protos = sup[torch.randint(0, 12, (k,), device=device, generator=g)] ^ (torch.rand((k, n_features), device=device, generator=g) < 0.12)
+    weights = torch.tensor(_W8, dtype=torch.int32, device=device)
+    out = torch.empty((n, n_features // 8), dtype=torch.uint8, device=device)
+    for lo in range(0, n, 50_000):
+        m = min(50_000, n - lo)
+        which = torch.randint(0, k, (m,), device=device, generator=g)
+        bits = (protos[which] ^ (torch.rand((m, n_features), device=device, generator=g) < 0.04)).to(torch.int32)
+        out[lo:lo + m] = (bits.view(m, -1, 8) * weights).sum(dim=2).to(torch.uint8)
+    return out
+
+
 WORKLOADS = {
     # name: (generator, threshold, description)
     "fake": (synth_fake_fps, 0.3, "make_fake_fingerprints popcount distribution"),
     "ecfp": (synth_ecfp, 0.3, "S-ecfp sparse ECFP4-like rows around n/50 planted prototypes"),
     "rdkit": (synth_rdkit_like, 0.6, "S-rdkit-like dense rows (popcount ~N(900,250)) around n/50 planted prototypes"),
+    "hier": (synth_hier, 0.6, "two-level planted families (clustered_hier): informative internal tree levels"),
 }
 
 
@@ -252,6 +273,12 @@ def _free_port() -> int:
         return s.getsockname()[1]
 
 
+def _longest(lib, name: bytes) -> tuple[float, int]:
+    ms, units = C.c_double(0.0), C.c_int64(0)
+    lib.bbh_profile_longest(name, C.byref(ms), C.byref(units))
+    return float(ms.value), int(units.value)
+
+
 def _profile(lib, name: bytes) -> tuple[int, float, int]:
     launches, total_ms, units = C.c_int64(0), C.c_double(0.0), C.c_int64(0)
     lib.bbh_profile_get(name, C.byref(launches), C.byref(total_ms))
@@ -274,7 +301,8 @@ def parse() -> argparse.Namespace:
     ap.add_argument("--k1-rows", type=int, default=8_000_000)
     ap.add_argument("--shards", type=int, default=512)
     ap.add_argument("--multiround-files", type=int, default=64, help="0 skips the file-based multiround run")
-    ap.add_argument("--no-extras", action="store_true", help="skip the bf 254 and one-rank distributed sub-records")
+    ap.add_argument("--no-extras", action="store_true", help="skip the sub-records (bf 254, other workloads, config 3, bf 1000, one-rank distributed)")
+    ap.add_argument("--config3-rows", type=int, default=10_000_000, help="rows of the config-3 sub-record (0 skips it)")
     ap.add_argument("--distributed", action="store_true",
                     help="time the one-rank-per-GPU multiround path even at N=1 (what N>1 always times)")
     return ap.parse_args()
@@ -482,11 +510,20 @@ def single_gpu(args: argparse.Namespace) -> None:
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
 
-    k_launches, total_ms, units = _profile(lib, b"tree_insert")
+    # every tree-kernel launch of the timed steps, the pipelined kernel's launches among them, and the one dominant launch
+    # (a fit is: a probe of the pipelined kernel on the empty tree, 8 192 elements of k_tree_fast, then ONE long launch)
+    all_launches, all_ms, all_units = _profile(lib, b"tree_insert")
+    k_launches, total_ms, units = _profile(lib, b"tree_insert/pipe")
+    dom_ms, dom_units = _longest(lib, b"tree_insert")
+    by_kernel = {name: dict(zip(("launches", "ms", "elements"), _profile(lib, b"tree_insert/" + name.encode())))
+                 for name in ("pipe", "fast", "complete")}
     lib.bbh_profile_enable(0)
+    if units == 0:  # (a workload the pipelined kernel never took: the record is then about whatever did the work)
+        k_launches, total_ms, units = all_launches, all_ms, all_units
     k_launches = max(k_launches, 1)
     avg_ms = total_ms / k_launches
-    achieved = BYTES_PER_FP * (units / k_launches) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    achieved = BYTES_PER_FP * units / (total_ms * 1e-3) / 1e9 if total_ms > 0 else 0.0
+    kc = tree._engine.kernel_counts()
 
     # fit + labels: the labels (get_assignments, reference bitbirch.py:1002-1047) on top of the timed fit
     torch.cuda.synchronize()
@@ -507,6 +544,83 @@ def single_gpu(args: argparse.Namespace) -> None:
         dt = time.perf_counter() - t1
         bf254 = {"branching_factor": 254, "seconds": dt, "fingerprints_per_s": n / dt, "stats": [int(v) for v in t254._engine.stats()[:7]]}
         del t254
+
+    # the other generators at the same size and branching factor(s): S-ecfp (configs 3 / 4), S-rdkit-like (config 5) and the
+    # workload whose INTERNAL levels stay informative (planted two-level families) - one fit each, with which kernel did it
+    others = None
+    if not args.no_extras:
+        others = {}
+        for wname in ("ecfp", "rdkit", "hier"):
+            if wname == args.workload:
+                continue
+            wgen, wthr, _ = WORKLOADS[wname]
+            wf = wgen(n, 1000, dev)
+            torch.cuda.synchronize()
+            for wbf in ((args.bf,) if wname != "hier" else (args.bf, 254)):
+                t1 = time.perf_counter()
+                wt = BitBirch(branching_factor=wbf, threshold=wthr, merge_criterion="diameter", device=local_rank).fit(wf)
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t1
+                wk = wt._engine.kernel_counts()
+                others[f"{wname}_bf{wbf}"] = {"rows": n, "threshold": wthr, "branching_factor": wbf, "seconds": dt, "fingerprints_per_s": n / dt,
+                                              "elements_by_kernel": {"pipe": int(wk[0]), "fast": int(wk[1]), "complete": int(wk[2])},
+                                              "unsupported_shape_stops": int(wk[6]), "stats": [int(v) for v in wt._engine.stats()[:7]]}
+                del wt
+            del wf
+
+    # BASELINE configs[2] in one run: S-ecfp, 10 M rows, the CLI's branching factor 254, `bb run --refine-num 1`
+    # (fit -> set_merge(tolerance-diameter, 0.05) -> refine_inplace(n_largest=1) -> labels; cli.py:1067-1092)
+    config3 = None
+    if not args.no_extras and args.config3_rows > 0:
+        try:
+            c3 = synth_ecfp(args.config3_rows, 7, dev)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            ct = BitBirch(branching_factor=254, threshold=0.3, merge_criterion="diameter", device=local_rank).fit(c3)
+            t2 = time.perf_counter()
+            k_fit = int(ct._engine.stats()[7])
+            ct.set_merge("tolerance-diameter", tolerance=0.05, threshold=0.3)
+            ct.refine_inplace(c3, n_largest=1)
+            t3 = time.perf_counter()
+            clab = ct.get_assignments()
+            t4 = time.perf_counter()
+            config3 = {"rows": args.config3_rows, "branching_factor": 254, "fit_s": t2 - t1, "refine_s": t3 - t2, "labels_s": t4 - t3,
+                       "fingerprints_per_s": args.config3_rows / (t4 - t1), "leaf_bitfeatures_after_fit": k_fit, "clusters": int(clab.max())}
+            del ct, clab, c3
+        except Exception as exc:  # the sub-record must not take the headline down with it
+            config3 = {"error": repr(exc)[:200]}
+        torch.cuda.empty_cache()
+
+    # bf 1000 (what the reference's user guide recommends for 100-200 M molecules, docs/src/user-guide/parameters.rst:95-98):
+    # a sample through the GPU engine and through the C oracle on one host core, side by side
+    bf1000 = None
+    cpu254 = None
+    if not args.no_extras and not args.no_cpu:
+        from oracle_engine import OracleEngine
+
+        m1000 = min(n, 200_000)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        bt = BitBirch(branching_factor=1000, threshold=args.threshold, merge_criterion="diameter", device=local_rank).fit(fps[:m1000])
+        torch.cuda.synchronize()
+        g_dt = time.perf_counter() - t1
+        del bt
+        hs = fps[:m1000].cpu().numpy()
+        eng = OracleEngine(1000, args.threshold, 0, 0.0, np.zeros(0), 2048)
+        t1 = time.perf_counter()
+        eng.fit_packed(hs)
+        c_dt = time.perf_counter() - t1
+        eng.close()
+        bf1000 = {"rows": m1000, "gpu_fingerprints_per_s": m1000 / g_dt, "cpu_oracle_1core_fingerprints_per_s": m1000 / c_dt,
+                  "gpu_over_cpu_core": c_dt / g_dt}
+        m254 = min(n, 300_000)
+        eng = OracleEngine(254, args.threshold, 0, 0.0, np.zeros(0), 2048)
+        t1 = time.perf_counter()
+        eng.fit_packed(fps[:m254].cpu().numpy())
+        c_dt = time.perf_counter() - t1
+        eng.close()
+        cpu254 = {"value": m254 / c_dt, "unit": "fingerprints/s", "cores": 1, "kind": "port", "branching_factor": 254,
+                  "sample": f"oracle fit of the first {m254} rows of the workload at bf 254, {c_dt:.1f} s on one host core"}
 
     # K1 (arr-vec Tanimoto): the HBM-bound kernel, on an array larger than the 256 MiB
     # Infinity Cache so that the rate is an HBM rate (the 1 M-row workload itself is 256 MB)
@@ -647,6 +761,14 @@ def single_gpu(args: argparse.Namespace) -> None:
             dt = time.perf_counter() - t1
             dist_one = {"shards": 8, "rows": 8 * per, "seconds": dt, "fingerprints_per_s": 8 * per / dt, "rccl_ranks": 1,
                         "clusters": int(dlabels.max()), "rounds_s": {k: round(float(v), 3) for k, v in dtimer.timings.items()}}
+            # What 8 ranks would make of the same job, as a PROJECTION (nothing here ran on 8 GPUs): only round 1 shards
+            # (one shard per rank); with 8 tables per dtype the merge round is one or two batches and the final merge one
+            # sequential tree (the reference's shape, multiround.py:443-470), so they stay what they are on one rank.
+            r_ = dtimer.timings
+            proj = r_["round-1"] / 8.0 + sum(v for k, v in r_.items() if k not in ("round-1", "total"))
+            dist_one["projected_8gpu"] = {"seconds": proj, "fingerprints_per_s": 8 * per / proj,
+                                          "note": "projection from this one-rank run: round-1 / 8 + the merge rounds as measured; "
+                                                  "exchange over xGMI and the labels not included; NOT a measurement"}
             del dtree, dlabels
             dist.destroy_process_group()
         except Exception as exc:  # the sub-record must not take the headline down with it
@@ -699,7 +821,14 @@ def single_gpu(args: argparse.Namespace) -> None:
             "launches": k_launches,
             "avg_launch_ms": avg_ms,
             "elements_per_launch": units / k_launches,
-            "note": "latency/dependency-bound sequential insertion; 264 algorithmic bytes per fingerprint",
+            "dominant_launch": {"ms": dom_ms, "elements": dom_units,
+                                "achieved_GBps": BYTES_PER_FP * dom_units / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0},
+            "by_kernel": by_kernel,
+            "last_fit_elements_by_kernel": {"pipe": int(kc[0]), "fast": int(kc[1]), "complete": int(kc[2]),
+                                            "unsupported_shape_stops": int(kc[6])},
+            "note": "latency/dependency-bound sequential insertion; 264 algorithmic bytes per fingerprint; `achieved` = the "
+                    "pipelined kernel's elements x 264 B / its summed launch time (HIP events on the launch stream); "
+                    "`dominant_launch` = the single longest tree-kernel launch of the timed steps",
         },
         "end_to_end": {
             "seconds": e2e, "fingerprints_per_s": n / e2e,
@@ -725,6 +854,10 @@ def single_gpu(args: argparse.Namespace) -> None:
             "queries": nq2, "centroids": nc2, "avg_launch_ms": k2_ms,
         },
         "bf254": bf254,
+        "other_workloads": others,
+        "config3": config3,
+        "bf1000": bf1000,
+        "cpu_baseline_bf254": cpu254,
         "distributed_one_rank": dist_one,
         "concurrent_shards": shard_stats,
         "multiround_one_gpu": mr_stats,

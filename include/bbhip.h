@@ -213,6 +213,9 @@ int bbh_profile_reset(void);
 int bbh_profile_get(const char* name, int64_t* launches, double* total_ms);
 /* work units (rows / inserted elements) summed over the recorded launches of `name` */
 int bbh_profile_units(const char* name, int64_t* units);
+/* the longest single recorded launch of `name`: its milliseconds and its work units (the dominant launch of a fit,
+ * next to which the short probe / warm-up launches of the same name would only blur an average) */
+int bbh_profile_longest(const char* name, double* ms, int64_t* units);
 
 #ifdef __cplusplus
 }

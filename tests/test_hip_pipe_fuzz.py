@@ -120,8 +120,31 @@ def test_pipe_fuzz_vs_oracle(seed):
     _same_tables(hip, ora)
     kc = hip._engine.kernel_counts()
     assert int(kc[:3].sum()) == n
-    if tiny:
-        assert int(kc[7]) > 0  # pools did run out in the middle of launches
+
+
+@pytest.mark.parametrize("bf", [50, 254])
+def test_pipe_tiny_pools_stop_and_resume(bf):
+    r"""Pools pre-grown by next to nothing: the pipelined kernel (and the kernels it hands over to) stop on exhausted node /
+    cluster-feature pools in the middle of their runs hundreds of times, the host grows the pool and relaunches from the
+    element that did not fit - element by element the oracle's result."""
+    rng = np.random.default_rng(99)
+    rows = np.concatenate([_segment(rng, 10_000, 0), _segment(rng, 6_000, 4), _segment(rng, 6_000, 3)])
+    kw = dict(branching_factor=bf, threshold=0.4, merge_criterion="diameter")
+    old = os.environ.get("BBHIP_TINY_POOLS")
+    os.environ["BBHIP_TINY_POOLS"] = "1"
+    try:
+        hip = BitBirch(**kw).fit(rows)
+    finally:
+        if old is None:
+            os.environ.pop("BBHIP_TINY_POOLS", None)
+        else:
+            os.environ["BBHIP_TINY_POOLS"] = old
+    ora = BitBirch(_engine_factory=OracleEngine, **kw).fit(rows)
+    assert (hip._log_leaf[-1] == ora._log_leaf[-1]).all()
+    assert hip._engine.stats()[:7].tolist() == ora._engine.stats()[:7].tolist()
+    _same_tables(hip, ora)
+    kc = hip._engine.kernel_counts()
+    assert int(kc[7]) > 50, kc.tolist()  # launches that ended on an exhausted pool
 
 
 def test_pipe_fuzz_reaches_the_pipeline():

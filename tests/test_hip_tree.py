@@ -352,6 +352,7 @@ def test_hip_pipelined_kernel_informative_internal_levels_vs_oracle(kind, bf, n,
     _same(hip, ora)
     kc = hip._engine.kernel_counts()
     assert int(kc[:3].sum()) == n
-    if bf == 50:
+    if bf == 50 and thr >= 0.5:
         # the pipelined kernel took the tree once it had a root above the leaves, several exact levels or not
+        # (at threshold 0.35 everything merges into a handful of clusters: the root stays a leaf, nothing to pipeline)
         assert int(kc[0]) > n // 2, kc.tolist()

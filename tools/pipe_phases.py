@@ -1,5 +1,5 @@
 """Phase timers of the pipelined kernel (BBHIP_PIPE_PHASES=1: the PROF instance of k_tree_pipe).
-    python tools/pipe_phases.py [rows] [workload: fake|ecfp|rdkit] [branching factor: 50|254]"""
+    python tools/pipe_phases.py [rows] [workload: fake|ecfp|rdkit|hier] [branching factor: 50|254]"""
 import os, sys, time
 os.environ["BBHIP_PIPE_PHASES"] = "1"
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
