@@ -3020,9 +3020,13 @@ static int insert_u8_buffers(bbh_tree* t, const uint8_t* d, int64_t m, const uin
                 hipError_t e = bb::dev_alloc(&packed, (size_t)m * nbytes);
                 if (e != hipSuccess) return bb::fail(BBH_ERR_HIP, "dev_alloc: %s", hipGetErrorString(e));
             }
-            const long long total = (long long)(hi - lo) * nbytes;
-            hipLaunchKernelGGL(k_pack_singletons, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, d + (size_t)lo * row_bytes,
-                               (long long)(hi - lo), t->h.F, nbytes, packed);
+            // (at most 2^22 rows per launch: the global size of a launch is a 32-bit number)
+            for (int64_t q = lo; q < hi; q += (4ll << 20)) {
+                const long long cnt = (long long)std::min<int64_t>(4ll << 20, hi - q);
+                const long long total = cnt * nbytes;
+                hipLaunchKernelGGL(k_pack_singletons, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, d + (size_t)q * row_bytes,
+                                   cnt, t->h.F, nbytes, packed + (size_t)(q - lo) * (size_t)nbytes);
+            }
             rc = run_insert(t, packed, nbytes, nullptr, 0, hi - lo, out ? out + lo : nullptr, s);
             lo = hi;
             continue;
@@ -3182,10 +3186,18 @@ static int gather(bbh_tree* t, const uint32_t* d_nodes, const uint32_t* d_rows, 
     BB_HIP(hipMemcpy(t->d, &h, sizeof(TreeDev), hipMemcpyHostToDevice));
     {
         bb::ProfScope ps("gather_leaves", nullptr);
-        hipLaunchKernelGGL(k_gather_leaves, dim3((unsigned)m), dim3(256), 0, nullptr, t->d, d_nodes, d_rows,
-                           (long long)m, width ? width : 1, (uint8_t*)ob.dev, ls_only, (uint8_t*)oc.dev,
-                           (unsigned long long*)on.dev, (uint32_t*)oi.dev);
-        BB_HIP(hipGetLastError());
+        // (a launch's global size - workgroups x 256 threads - is a 32-bit number: more than 2^24 leaves in ONE launch ran
+        // only m mod 2^24 of them, silently; found at 20 M leaf BitFeatures in round 4)
+        const int64_t kMax = 4ll << 20;
+        const int w = width ? width : 1;
+        for (int64_t lo = 0; lo < m; lo += kMax) {
+            const int64_t cnt = std::min(kMax, m - lo);
+            hipLaunchKernelGGL(k_gather_leaves, dim3((unsigned)cnt), dim3(256), 0, nullptr, t->d, d_nodes + lo, d_rows + lo,
+                               (long long)cnt, w, ob.dev ? (uint8_t*)ob.dev + (size_t)lo * cols * (size_t)w : nullptr, ls_only,
+                               oc.dev ? (uint8_t*)oc.dev + (size_t)lo * (size_t)h.nbytes : nullptr,
+                               on.dev ? (unsigned long long*)on.dev + lo : nullptr, oi.dev ? (uint32_t*)oi.dev + lo : nullptr);
+            BB_HIP(hipGetLastError());
+        }
     }
     BB_TRY(ob.finish(nullptr));
     BB_TRY(oc.finish(nullptr));

@@ -144,7 +144,7 @@ def test_pipe_tiny_pools_stop_and_resume(bf):
     assert hip._engine.stats()[:7].tolist() == ora._engine.stats()[:7].tolist()
     _same_tables(hip, ora)
     kc = hip._engine.kernel_counts()
-    assert int(kc[7]) > 50, kc.tolist()  # launches that ended on an exhausted pool
+    assert int(kc[7]) > 5, kc.tolist()  # launches that ended on an exhausted pool
 
 
 def test_pipe_fuzz_reaches_the_pipeline():
