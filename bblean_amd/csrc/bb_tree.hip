@@ -2340,13 +2340,182 @@ struct bbh_tree {
 
 namespace {
 
+// ---- pools that grow in place --------------------------------------------------------------------------------------
+// A tree of tens of millions of leaf BitFeatures owns pools of tens of GB (at bf 254 a node is 75 KB whatever it holds, and
+// the splits of rows that hardly merge leave the leaves a tenth full: 3 GB of node rows per million fingerprints of S-ecfp).
+// Growing such a pool by allocate-copy-free needs old and new side by side - at 20 M rows that, not the tree, was what filled
+// the 288 GB.  Pools beyond kVmmMin therefore live in a RESERVED virtual range and grow by mapping more physical memory behind
+// what is there (hipMemAddressReserve / hipMemCreate / hipMemMap): nothing is copied, nothing is held twice, the pool's
+// address does not change until the reservation itself (four times the pool) is used up - and then the physical chunks are
+// mapped again into a larger range, still without a copy.  BBHIP_NO_VMM=1 (or a runtime without the calls) keeps the
+// allocate-copy-free path.
+struct VRegion {
+    size_t reserved = 0, mapped = 0;
+    std::vector<std::pair<hipMemGenericAllocationHandle_t, size_t>> chunks;
+};
+static std::mutex g_vr_mu;
+static std::map<void*, VRegion> g_vr;  // by base address
+constexpr size_t kVmmMin = 256ull << 20;
+
+static bool vmm_usable(int device, size_t* gran_out) {
+    static int state = -1;  // -1 unknown, 0 no, 1 yes
+    static size_t gran = 0;
+    if (state < 0) {
+        state = 0;
+        const char* e = getenv("BBHIP_NO_VMM");
+        if (!(e && e[0] != '\0' && std::strcmp(e, "0") != 0)) {
+            hipMemAllocationProp prop{};
+            prop.type = hipMemAllocationTypePinned;
+            prop.location.type = hipMemLocationTypeDevice;
+            prop.location.id = device;
+            size_t g = 0;
+            if (hipMemGetAllocationGranularity(&g, &prop, hipMemAllocationGranularityRecommended) == hipSuccess && g > 0) {
+                // (one round trip through the calls: a runtime that only declares them answers with an error here)
+                void* va = nullptr;
+                hipMemGenericAllocationHandle_t h{};
+                if (hipMemAddressReserve(&va, g, 0, nullptr, 0) == hipSuccess) {
+                    if (hipMemCreate(&h, g, &prop, 0) == hipSuccess) {
+                        if (hipMemMap(va, g, 0, h, 0) == hipSuccess) {
+                            hipMemAccessDesc acc{};
+                            acc.location = prop.location;
+                            acc.flags = hipMemAccessFlagsProtReadWrite;
+                            if (hipMemSetAccess(va, g, &acc, 1) == hipSuccess) { state = 1; gran = g; }
+                            (void)hipMemUnmap(va, g);
+                        }
+                        (void)hipMemRelease(h);
+                    }
+                    (void)hipMemAddressFree(va, g);
+                }
+            }
+            (void)hipGetLastError();
+        }
+    }
+    if (gran_out) *gran_out = gran;
+    return state == 1;
+}
+
+// maps `bytes` more (a multiple of the granularity) behind what `base` has mapped
+static hipError_t vr_map_more(void* base, VRegion& r, size_t bytes, int device) {
+    hipMemAllocationProp prop{};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = device;
+    hipMemGenericAllocationHandle_t h{};
+    hipError_t e = hipMemCreate(&h, bytes, &prop, 0);
+    if (e != hipSuccess) {  // the library's cache of freed blocks may be what is in the way
+        (void)hipGetLastError();
+        bb::dev_trim();
+        e = hipMemCreate(&h, bytes, &prop, 0);
+        if (e != hipSuccess) return e;
+    }
+    e = hipMemMap((char*)base + r.mapped, bytes, 0, h, 0);
+    if (e != hipSuccess) { (void)hipMemRelease(h); return e; }
+    hipMemAccessDesc acc{};
+    acc.location = prop.location;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    e = hipMemSetAccess((char*)base + r.mapped, bytes, &acc, 1);
+    if (e != hipSuccess) { (void)hipMemUnmap((char*)base + r.mapped, bytes); (void)hipMemRelease(h); return e; }
+    r.chunks.emplace_back(h, bytes);
+    r.mapped += bytes;
+    return hipSuccess;
+}
+
+static void vr_release(void* base, VRegion& r) {
+    size_t off = 0;
+    for (auto& c : r.chunks) {
+        (void)hipMemUnmap((char*)base + off, c.second);
+        (void)hipMemRelease(c.first);
+        off += c.second;
+    }
+    (void)hipMemAddressFree(base, r.reserved);
+}
+
+// frees a pool, whichever way it was allocated
+static void pool_free(void* p) {
+    if (!p) return;
+    {
+        std::lock_guard<std::mutex> lk(g_vr_mu);
+        auto it = g_vr.find(p);
+        if (it != g_vr.end()) {
+            vr_release(p, it->second);
+            g_vr.erase(it);
+            return;
+        }
+    }
+    bb::dev_free(p);
+}
+
 // `used_elems`: the prefix of the old pool that holds live data (only that much is carried over)
 template <typename T>
 int grow_pool(T*& p, size_t used_elems, size_t new_elems) {
+    const size_t need = new_elems * sizeof(T) + 64;  // slack: cf_load_raw over-reads 8 bytes
+    int device = 0;
+    (void)hipGetDevice(&device);
+    size_t gran = 0;
+    if (need >= kVmmMin && vmm_usable(device, &gran)) {
+        std::lock_guard<std::mutex> lk(g_vr_mu);
+        const size_t want = (need + gran - 1) / gran * gran;
+        auto it = p ? g_vr.find((void*)p) : g_vr.end();
+        if (it != g_vr.end() && want <= it->second.reserved) {
+            // in place: more physical memory behind what is there
+            if (want > it->second.mapped) {
+                hipError_t e = vr_map_more((void*)p, it->second, want - it->second.mapped, device);
+                if (e != hipSuccess) return bb::fail(BBH_ERR_HIP, "growing a pool to %zu MB in place: %s", want >> 20, hipGetErrorString(e));
+            }
+            return BBH_OK;
+        }
+        // a new (larger) reservation
+        const size_t res = std::max<size_t>(4 * want, 1ull << 30);
+        void* va = nullptr;
+        if (hipMemAddressReserve(&va, res, 0, nullptr, 0) == hipSuccess) {
+            VRegion nr;
+            nr.reserved = res;
+            hipError_t e = hipSuccess;
+            if (it != g_vr.end()) {
+                // the pool's physical chunks move to the new range: unmapped there, mapped here, no copy
+                VRegion& orr = it->second;
+                hipMemAccessDesc acc{};
+                acc.location.type = hipMemLocationTypeDevice;
+                acc.location.id = device;
+                acc.flags = hipMemAccessFlagsProtReadWrite;
+                size_t off = 0;
+                for (auto& c : orr.chunks) {
+                    if (e == hipSuccess) e = hipMemUnmap((char*)p + off, c.second);
+                    if (e == hipSuccess) e = hipMemMap((char*)va + off, c.second, 0, c.first, 0);
+                    if (e == hipSuccess) e = hipMemSetAccess((char*)va + off, c.second, &acc, 1);
+                    off += c.second;
+                }
+                if (e != hipSuccess) return bb::fail(BBH_ERR_HIP, "moving a pool's memory to a larger address range: %s", hipGetErrorString(e));
+                nr.chunks = std::move(orr.chunks);
+                nr.mapped = orr.mapped;
+                (void)hipMemAddressFree((void*)p, orr.reserved);
+                g_vr.erase(it);
+                if (want > nr.mapped) e = vr_map_more(va, nr, want - nr.mapped, device);
+                if (e != hipSuccess) { g_vr[va] = nr; p = (T*)va; return bb::fail(BBH_ERR_HIP, "growing a pool to %zu MB: %s", want >> 20, hipGetErrorString(e)); }
+                g_vr[va] = nr;
+                p = (T*)va;
+                return BBH_OK;
+            }
+            e = vr_map_more(va, nr, want, device);
+            if (e == hipSuccess) {
+                if (p && used_elems) e = hipMemcpy(va, p, used_elems * sizeof(T), hipMemcpyDeviceToDevice);
+                if (e == hipSuccess) {
+                    if (p) bb::dev_free(p);
+                    g_vr[va] = nr;
+                    p = (T*)va;
+                    return BBH_OK;
+                }
+            }
+            vr_release(va, nr);  // (fall back to the copying path below)
+            (void)hipGetLastError();
+        } else {
+            (void)hipGetLastError();
+        }
+    }
     T* np_ = nullptr;
-    BB_HIP(bb::dev_alloc(&np_, new_elems * sizeof(T) + 64));  // slack: cf_load_raw over-reads 8 bytes
+    BB_HIP(bb::dev_alloc(&np_, need));
     if (p && used_elems) BB_HIP(hipMemcpy(np_, p, used_elems * sizeof(T), hipMemcpyDeviceToDevice));
-    if (p) bb::dev_free(p);
+    if (p) pool_free((void*)p);
     p = np_;
     return BBH_OK;
 }
@@ -2411,7 +2580,7 @@ void free_pools(bbh_tree* t) {
     TreeDev& h = t->h;
     void* ptrs[] = {h.node_cent, h.node_card, h.node_link, h.node_rm, h.node_hdr, h.scratch_cent, h.cf8, h.cf16, h.cf32};
     for (void* p : ptrs)
-        if (p) bb::dev_free(p);
+        if (p) pool_free(p);
     h.node_cent = nullptr; h.node_card = nullptr; h.node_link = nullptr; h.node_rm = nullptr; h.node_hdr = nullptr;
     h.scratch_cent = nullptr; h.cf8 = nullptr; h.cf16 = nullptr; h.cf32 = nullptr;
     h.cap_nodes = h.cap8 = h.cap16 = h.cap32 = 0;

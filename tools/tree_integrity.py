@@ -22,6 +22,8 @@ dt = time.perf_counter() - t0
 lv = t._leaves()
 sizes = (lv["end"] - lv["beg"]).astype(np.int64)
 nn = lv["n"].astype(np.int64)
+free, total = torch.cuda.mem_get_info()
+print(f"HBM in use after the fit {(total - free) / 2**30:.1f} GiB (input {fps.numel() / 2**30:.1f} GiB)")
 print(f"{workload} bf {bf}: {n / dt:.0f} fps/s; leaves {nn.size}, min n {nn.min()}, sum n {nn.sum()} (rows {n}), host/device size mismatches {(sizes != nn).sum()}; "
       f"stats {t._engine.stats().tolist()} kernels {t._engine.kernel_counts().tolist()}", flush=True)
 bad = np.nonzero(sizes != nn)[0]
