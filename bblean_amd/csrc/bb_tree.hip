@@ -2362,8 +2362,8 @@ static bool vmm_usable(int device, size_t* gran_out) {
     static size_t gran = 0;
     if (state < 0) {
         state = 0;
-        const char* e = getenv("BBHIP_NO_VMM");
-        if (!(e && e[0] != '\0' && std::strcmp(e, "0") != 0)) {
+        const char* e = getenv("BBHIP_VMM");  // (opt-in until the runtime's behaviour is pinned down: tools/probe/vmm_probe.cpp)
+        if (e && e[0] != '\0' && std::strcmp(e, "0") != 0) {
             hipMemAllocationProp prop{};
             prop.type = hipMemAllocationTypePinned;
             prop.location.type = hipMemLocationTypeDevice;
