@@ -2336,6 +2336,13 @@ struct bbh_tree {
     // the launches the pipelined kernel ended with STOP_PIPE_UNSUPPORTED and the pool-exhaustion stops (STOP_NODES / STOP_CF*)
     uint64_t kcount[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     bool pipe_ml = false;  // the pipelined kernel asked for its multi-level instance (informative levels above the leaf-parents)
+    // Pool sizing.  `inserted`: elements this tree has taken since it was reset; `expected`: elements the caller has announced
+    // (bbh_tree_expect: a merge round knows how many BitFeatures its tables hold) that have not arrived yet.  Once a tree
+    // has taken a few thousand elements its own rates (nodes / tracking cluster features / uint8 slots per element) size the
+    // pools for everything that is still to come in ONE step - a pool of tens of GB that grows by halves is held twice,
+    // old next to new, at every step.
+    uint64_t inserted = 0;
+    int64_t expected = 0;
 };
 
 namespace {
@@ -2379,7 +2386,8 @@ static bool vmm_usable(int device, size_t* gran_out) {
                             hipMemAccessDesc acc{};
                             acc.location = prop.location;
                             acc.flags = hipMemAccessFlagsProtReadWrite;
-                            if (hipMemSetAccess(va, g, &acc, 1) == hipSuccess) { state = 1; gran = g; }
+                            // (chunks are sized in multiples of 2 MiB whatever the minimum is: large mappings want the fragment size)
+                            if (hipMemSetAccess(va, g, &acc, 1) == hipSuccess) { state = 1; gran = std::max<size_t>(g, 2u << 20); }
                             (void)hipMemUnmap(va, g);
                         }
                         (void)hipMemRelease(h);
@@ -2534,10 +2542,28 @@ static uint32_t grow_target(uint32_t cap, uint32_t want) {
     return (uint32_t)std::min<uint64_t>(0x3FFFFFFFull, std::max<uint64_t>(want, geo));
 }
 
+uint32_t clamp30(uint64_t v) { return (uint32_t)std::min<uint64_t>(0x3FFFFFFFull, v); }
+
+// a generous target (grow_target's half-as-much-again, the rate-based estimates of pregrow) must not be what runs the device
+// out of memory: beyond `floor_elems` (what is needed now) the pool only takes what the driver reports free, less a tenth
+static uint32_t fit_to_memory(uint32_t want, uint32_t floor_elems, uint32_t cap, size_t elem_bytes) {
+    if (want <= floor_elems) return want;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return want; }
+    // (the copying growth holds the old pool until the new one is filled: only the free memory counts)
+    const size_t room = (size_t)((double)free_b * 0.9) / std::max<size_t>(elem_bytes, 1);
+    const uint64_t most = std::max<uint64_t>(floor_elems, std::min<uint64_t>(want, room));
+    return (uint32_t)std::min<uint64_t>(most, 0x3FFFFFFFull);
+}
+
 int grow_nodes(bbh_tree* t, uint32_t want) {
     TreeDev& h = t->h;
     if (want <= h.cap_nodes) return BBH_OK;
-    want = grow_target(h.cap_nodes, want);
+    {
+        const uint32_t floor_elems = clamp30((uint64_t)h.ctr[C_NODES] + 2 * (uint64_t)h.ctr[C_DEPTH] + 64);
+        want = fit_to_memory(grow_target(h.cap_nodes, want), std::max(floor_elems, h.cap_nodes + 1), h.cap_nodes,
+                             ((size_t)h.bf + 1) * ((size_t)h.RB + 40) + 16);
+    }
     const size_t rows = (size_t)h.bf + 1;
     // a tree that has not received anything yet owns one empty root: nothing to carry over but its
     // 16-byte header (a multiround round creates hundreds of trees and grows each of them once)
@@ -2561,15 +2587,15 @@ int grow_cf(bbh_tree* t, int tier, uint32_t want) {
     TreeDev& h = t->h;
     const size_t F = (size_t)h.F;
     if (tier == 0 && want > h.cap8) {
-        want = grow_target(h.cap8, want);
+        want = fit_to_memory(grow_target(h.cap8, want), std::max<uint32_t>(clamp30((uint64_t)h.ctr[C_N8] + 2 * (uint64_t)h.ctr[C_DEPTH] + 64), h.cap8 + 1), h.cap8, F * 1);
         BB_TRY(grow_pool(h.cf8, (size_t)std::min(h.cap8, h.ctr[C_N8]) * F, (size_t)want * F));
         h.cap8 = want;
     } else if (tier == 1 && want > h.cap16) {
-        want = grow_target(h.cap16, want);
+        want = fit_to_memory(grow_target(h.cap16, want), std::max<uint32_t>(clamp30((uint64_t)h.ctr[C_N16] + 2 * (uint64_t)h.ctr[C_DEPTH] + 64), h.cap16 + 1), h.cap16, F * 2);
         BB_TRY(grow_pool(h.cf16, (size_t)std::min(h.cap16, h.ctr[C_N16]) * F, (size_t)want * F));
         h.cap16 = want;
     } else if (tier == 2 && want > h.cap32) {
-        want = grow_target(h.cap32, want);
+        want = fit_to_memory(grow_target(h.cap32, want), std::max<uint32_t>(clamp30((uint64_t)h.ctr[C_N32] + 2 * (uint64_t)h.ctr[C_DEPTH] + 64), h.cap32 + 1), h.cap32, F * 4);
         BB_TRY(grow_pool(h.cf32, (size_t)std::min(h.cap32, h.ctr[C_N32]) * F, (size_t)want * F));
         h.cap32 = want;
     }
@@ -2610,6 +2636,8 @@ int init_empty(bbh_tree* t) {
     t->chain_valid = false;
     t->pipe_ml = false;
     t->unsup_stretch = 0;
+    t->inserted = 0;
+    t->expected = 0;
     return BBH_OK;
 }
 
@@ -2697,7 +2725,6 @@ static bool dense_launch(size_t n_trees, size_t lds_bytes) {
     return n_trees > (size_t)cus && 2 * lds_bytes <= 160 * 1024;
 }
 
-uint32_t clamp30(uint64_t v) { return (uint32_t)std::min<uint64_t>(0x3FFFFFFFull, v); }
 
 // Pools are grown BEFORE a call to what its n elements are expected to need; a kernel that runs out anyway stops in front of
 // the element that does not fit (STOP_NODES / STOP_CF*) and the host grows the pool and relaunches (run_insert_multi).
@@ -2705,6 +2732,14 @@ uint32_t clamp30(uint64_t v) { return (uint32_t)std::min<uint64_t>(0x3FFFFFFFull
 //   appended buffer of several members - an eighth of the elements is more than any workload measured took (S-fake 3 %,
 //   S-ecfp 1 %, S-rdkit-like 10 %); nodes: one per bf / 2 elements (a node is half full after its split); tracking cluster
 //   features (uint32): two per node split.
+// what `todo` more elements are expected to take of a pool of which the tree's `inserted` elements took `used` (15 % on top),
+// or `fallback` while the tree is too young to know its own rates
+static uint64_t by_rate(const bbh_tree* t, uint32_t used, uint64_t todo, uint64_t fallback) {
+    if (t->inserted < 16384) return fallback;
+    const double rate = (double)used / (double)t->inserted;
+    return (uint64_t)(rate * (double)todo * 1.15) + 4096;
+}
+
 int pregrow(bbh_tree* t, int64_t n, int width) {
     TreeDev& h = t->h;
     if (tiny_pools()) {
@@ -2714,10 +2749,12 @@ int pregrow(bbh_tree* t, int64_t n, int width) {
         BB_TRY(grow_cf(t, 2, clamp30((uint64_t)h.ctr[C_N32] + 16 + 2 * (uint64_t)h.ctr[C_DEPTH])));
         return BBH_OK;
     }
-    if (width <= 1) BB_TRY(grow_cf(t, 0, clamp30((uint64_t)h.ctr[C_N8] + (uint64_t)n / 8 + 1024)));
-    if (width == 2) BB_TRY(grow_cf(t, 1, clamp30((uint64_t)h.ctr[C_N16] + (uint64_t)n + 64)));
-    BB_TRY(grow_nodes(t, clamp30((uint64_t)h.ctr[C_NODES] + (uint64_t)n / std::max(1, h.bf / 2) + 64)));
-    BB_TRY(grow_cf(t, 2, clamp30((uint64_t)h.ctr[C_N32] + (uint64_t)n / std::max(1, h.bf / 6) + 256)));
+    const uint64_t un = (uint64_t)std::max<int64_t>(n, 0);
+    const uint64_t todo = std::max<uint64_t>(un, (uint64_t)std::max<int64_t>(t->expected, 0));  // this call, or everything announced
+    if (width <= 1) BB_TRY(grow_cf(t, 0, clamp30((uint64_t)h.ctr[C_N8] + by_rate(t, h.ctr[C_N8], todo, un / 8 + 1024))));
+    if (width == 2) BB_TRY(grow_cf(t, 1, clamp30((uint64_t)h.ctr[C_N16] + un + 64)));
+    BB_TRY(grow_nodes(t, clamp30((uint64_t)h.ctr[C_NODES] + by_rate(t, h.ctr[C_NODES], todo, un / (uint64_t)std::max(1, h.bf / 2) + 64))));
+    BB_TRY(grow_cf(t, 2, clamp30((uint64_t)h.ctr[C_N32] + by_rate(t, h.ctr[C_N32], todo, un / (uint64_t)std::max(1, h.bf / 6) + 256))));
     return BBH_OK;
 }
 
@@ -2905,6 +2942,8 @@ int run_insert_multi(std::vector<Job>& jobs, hipStream_t s) {
             {
                 const int kk = log_kernel[0] == 'p' ? 0 : (log_kernel[0] == 'f' ? 1 : 2);
                 t->kcount[kk] += (uint64_t)back.processed;
+                t->inserted += (uint64_t)back.processed;
+                t->expected = std::max<int64_t>(0, t->expected - back.processed);
                 t->kcount[3 + kk] += 1;
                 if (back.stop_reason == STOP_PIPE_UNSUPPORTED) t->kcount[6] += 1;
                 if (back.stop_reason == STOP_NODES || back.stop_reason == STOP_CF8 || back.stop_reason == STOP_CF16 || back.stop_reason == STOP_CF32) t->kcount[7] += 1;
@@ -2921,12 +2960,13 @@ int run_insert_multi(std::vector<Job>& jobs, hipStream_t s) {
                 return clamp30(std::max<uint64_t>((uint64_t)cap + cap / 2, (uint64_t)used + expect));
             };
             const uint64_t uleft = (uint64_t)std::max<int64_t>(left, 0);
+            const uint64_t todo = std::max<uint64_t>(uleft, (uint64_t)std::max<int64_t>(t->expected, 0));  // (what is left of this call, or of everything announced)
             switch (back.stop_reason) {
                 case STOP_DONE: break;
-                case STOP_NODES: rc = grow_nodes(t, more(h.ctr[C_NODES], h.cap_nodes, uleft / (uint64_t)std::max(1, h.bf / 2) + 64)); break;
-                case STOP_CF8: rc = grow_cf(t, 0, more(h.ctr[C_N8], h.cap8, uleft / 8 + 1024)); break;
+                case STOP_NODES: rc = grow_nodes(t, more(h.ctr[C_NODES], h.cap_nodes, by_rate(t, h.ctr[C_NODES], todo, uleft / (uint64_t)std::max(1, h.bf / 2) + 64))); break;
+                case STOP_CF8: rc = grow_cf(t, 0, more(h.ctr[C_N8], h.cap8, by_rate(t, h.ctr[C_N8], todo, uleft / 8 + 1024))); break;
                 case STOP_CF16: rc = grow_cf(t, 1, more(h.ctr[C_N16], h.cap16, (j.width == 2 ? uleft : uleft / 64) + 64)); break;
-                case STOP_CF32: rc = grow_cf(t, 2, more(h.ctr[C_N32], h.cap32, uleft / (uint64_t)std::max(1, h.bf / 6) + 256)); break;
+                case STOP_CF32: rc = grow_cf(t, 2, more(h.ctr[C_N32], h.cap32, by_rate(t, h.ctr[C_N32], todo, uleft / (uint64_t)std::max(1, h.bf / 6) + 256))); break;
                 case STOP_DEPTH: rc = bb::fail(BBH_ERR_CAPACITY, "tree deeper than %d levels (or corrupt link)", MAXD); break;
                 case STOP_RANGE: rc = bb::fail(BBH_ERR_INVALID, "n_samples exceeds 2^32-1 (engine limit)"); break;
                 case STOP_PIPE_UNSUPPORTED:
@@ -3422,6 +3462,12 @@ extern "C" int bbh_tree_gather_centroids(bbh_tree* t, const int64_t* positions, 
     if (!t || (m > 0 && (!positions || !out))) return bb::fail(BBH_ERR_INVALID, "null argument");
     if (m == 0) return BBH_OK;
     return gather_positions(t, positions, m, 0, nullptr, out);
+}
+
+extern "C" int bbh_tree_expect(bbh_tree* t, int64_t n_elements) {
+    if (!t || n_elements < 0) return bb::fail(BBH_ERR_INVALID, "bbh_tree_expect: null tree or negative count");
+    t->expected = n_elements;
+    return BBH_OK;
 }
 
 extern "C" int bbh_tree_kernel_counts(bbh_tree* t, uint64_t* out8) {
