@@ -367,10 +367,6 @@ class HipEngine:
         _lib.check(self._lib.bbh_tree_stats(self._h, out.ctypes.data))
         return out
 
-    def expect(self, n_elements: int) -> None:
-        r"""Announce how many elements the following fit calls will bring (a hint for the sizing of the tree's pools)."""
-        _lib.check(self._lib.bbh_tree_expect(self._h, int(n_elements)))
-
     def kernel_counts(self) -> NDArray[np.uint64]:
         r"""[0..2] elements inserted by the pipelined / steady-state / complete kernel, [3..5] their launches, [6] launches
         that ended with "tree shape not handled by the pipeline", [7] launches that ended on an exhausted pool."""

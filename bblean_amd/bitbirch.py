@@ -381,13 +381,6 @@ class BitBirch:
         self._num_fitted_fps += int(ids.size)
         self._cache.clear()
 
-    def _announce(self, n_features: int, n_elements: int) -> None:
-        r"""A sizing hint for the engine: `n_elements` elements are about to be inserted over several calls."""
-        self._ensure_engine(n_features)
-        expect = getattr(self._engine, "expect", None)
-        if expect is not None:
-            expect(n_elements)
-
     def fit_reinsert(self, X, reinsert_indices, input_is_packed=True, n_features=None, max_fps=None):  # type: ignore[no-untyped-def]
         r""":meta private: (reference bitbirch.py:868-878)"""
         return self.fit(X, reinsert_indices, input_is_packed, n_features, max_fps)

@@ -2336,194 +2336,21 @@ struct bbh_tree {
     // the launches the pipelined kernel ended with STOP_PIPE_UNSUPPORTED and the pool-exhaustion stops (STOP_NODES / STOP_CF*)
     uint64_t kcount[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     bool pipe_ml = false;  // the pipelined kernel asked for its multi-level instance (informative levels above the leaf-parents)
-    // Pool sizing.  `inserted`: elements this tree has taken since it was reset; `expected`: elements the caller has announced
-    // (bbh_tree_expect: a merge round knows how many BitFeatures its tables hold) that have not arrived yet.  Once a tree
-    // has taken a few thousand elements its own rates (nodes / tracking cluster features / uint8 slots per element) size the
-    // pools for everything that is still to come in ONE step - a pool of tens of GB that grows by halves is held twice,
-    // old next to new, at every step.
-    uint64_t inserted = 0;
-    int64_t expected = 0;
 };
 
 namespace {
 
-// ---- pools that grow in place --------------------------------------------------------------------------------------
-// A tree of tens of millions of leaf BitFeatures owns pools of tens of GB (at bf 254 a node is 75 KB whatever it holds, and
-// the splits of rows that hardly merge leave the leaves a tenth full: 3 GB of node rows per million fingerprints of S-ecfp).
-// Growing such a pool by allocate-copy-free needs old and new side by side - at 20 M rows that, not the tree, was what filled
-// the 288 GB.  Pools beyond kVmmMin therefore live in a RESERVED virtual range and grow by mapping more physical memory behind
-// what is there (hipMemAddressReserve / hipMemCreate / hipMemMap): nothing is copied, nothing is held twice, the pool's
-// address does not change until the reservation itself (four times the pool) is used up - and then the physical chunks are
-// mapped again into a larger range, still without a copy.  BBHIP_NO_VMM=1 (or a runtime without the calls) keeps the
-// allocate-copy-free path.
-struct VRegion {
-    size_t reserved = 0, mapped = 0;
-    std::vector<std::pair<hipMemGenericAllocationHandle_t, size_t>> chunks;
-};
-static std::mutex g_vr_mu;
-static std::map<void*, VRegion> g_vr;  // by base address
-constexpr size_t kVmmMin = 256ull << 20;
-
-static bool vmm_usable(int device, size_t* gran_out) {
-    static int state = -1;  // -1 unknown, 0 no, 1 yes
-    static size_t gran = 0;
-    if (state < 0) {
-        state = 0;
-        const char* e = getenv("BBHIP_VMM");  // (opt-in until the runtime's behaviour is pinned down: tools/probe/vmm_probe.cpp)
-        if (e && e[0] != '\0' && std::strcmp(e, "0") != 0) {
-            hipMemAllocationProp prop{};
-            prop.type = hipMemAllocationTypePinned;
-            prop.location.type = hipMemLocationTypeDevice;
-            prop.location.id = device;
-            size_t g = 0;
-            if (hipMemGetAllocationGranularity(&g, &prop, hipMemAllocationGranularityRecommended) == hipSuccess && g > 0) {
-                // (one round trip through the calls: a runtime that only declares them answers with an error here)
-                void* va = nullptr;
-                hipMemGenericAllocationHandle_t h{};
-                if (hipMemAddressReserve(&va, g, 0, nullptr, 0) == hipSuccess) {
-                    if (hipMemCreate(&h, g, &prop, 0) == hipSuccess) {
-                        if (hipMemMap(va, g, 0, h, 0) == hipSuccess) {
-                            hipMemAccessDesc acc{};
-                            acc.location = prop.location;
-                            acc.flags = hipMemAccessFlagsProtReadWrite;
-                            // (chunks are sized in multiples of 2 MiB whatever the minimum is: large mappings want the fragment size)
-                            if (hipMemSetAccess(va, g, &acc, 1) == hipSuccess) { state = 1; gran = std::max<size_t>(g, 2u << 20); }
-                            (void)hipMemUnmap(va, g);
-                        }
-                        (void)hipMemRelease(h);
-                    }
-                    (void)hipMemAddressFree(va, g);
-                }
-            }
-            (void)hipGetLastError();
-        }
-    }
-    if (gran_out) *gran_out = gran;
-    return state == 1;
-}
-
-// maps `bytes` more (a multiple of the granularity) behind what `base` has mapped
-static hipError_t vr_map_more(void* base, VRegion& r, size_t bytes, int device) {
-    hipMemAllocationProp prop{};
-    prop.type = hipMemAllocationTypePinned;
-    prop.location.type = hipMemLocationTypeDevice;
-    prop.location.id = device;
-    hipMemGenericAllocationHandle_t h{};
-    hipError_t e = hipMemCreate(&h, bytes, &prop, 0);
-    if (e != hipSuccess) {  // the library's cache of freed blocks may be what is in the way
-        (void)hipGetLastError();
-        bb::dev_trim();
-        e = hipMemCreate(&h, bytes, &prop, 0);
-        if (e != hipSuccess) return e;
-    }
-    e = hipMemMap((char*)base + r.mapped, bytes, 0, h, 0);
-    if (e != hipSuccess) { (void)hipMemRelease(h); return e; }
-    hipMemAccessDesc acc{};
-    acc.location = prop.location;
-    acc.flags = hipMemAccessFlagsProtReadWrite;
-    e = hipMemSetAccess((char*)base + r.mapped, bytes, &acc, 1);
-    if (e != hipSuccess) { (void)hipMemUnmap((char*)base + r.mapped, bytes); (void)hipMemRelease(h); return e; }
-    r.chunks.emplace_back(h, bytes);
-    r.mapped += bytes;
-    return hipSuccess;
-}
-
-static void vr_release(void* base, VRegion& r) {
-    size_t off = 0;
-    for (auto& c : r.chunks) {
-        (void)hipMemUnmap((char*)base + off, c.second);
-        (void)hipMemRelease(c.first);
-        off += c.second;
-    }
-    (void)hipMemAddressFree(base, r.reserved);
-}
-
-// frees a pool, whichever way it was allocated
-static void pool_free(void* p) {
-    if (!p) return;
-    {
-        std::lock_guard<std::mutex> lk(g_vr_mu);
-        auto it = g_vr.find(p);
-        if (it != g_vr.end()) {
-            vr_release(p, it->second);
-            g_vr.erase(it);
-            return;
-        }
-    }
-    bb::dev_free(p);
-}
-
 // `used_elems`: the prefix of the old pool that holds live data (only that much is carried over)
 template <typename T>
 int grow_pool(T*& p, size_t used_elems, size_t new_elems) {
-    const size_t need = new_elems * sizeof(T) + 64;  // slack: cf_load_raw over-reads 8 bytes
-    int device = 0;
-    (void)hipGetDevice(&device);
-    size_t gran = 0;
-    if (need >= kVmmMin && vmm_usable(device, &gran)) {
-        std::lock_guard<std::mutex> lk(g_vr_mu);
-        const size_t want = (need + gran - 1) / gran * gran;
-        auto it = p ? g_vr.find((void*)p) : g_vr.end();
-        if (it != g_vr.end() && want <= it->second.reserved) {
-            // in place: more physical memory behind what is there
-            if (want > it->second.mapped) {
-                hipError_t e = vr_map_more((void*)p, it->second, want - it->second.mapped, device);
-                if (e != hipSuccess) return bb::fail(BBH_ERR_HIP, "growing a pool to %zu MB in place: %s", want >> 20, hipGetErrorString(e));
-            }
-            return BBH_OK;
-        }
-        // a new (larger) reservation
-        const size_t res = std::max<size_t>(4 * want, 1ull << 30);
-        void* va = nullptr;
-        if (hipMemAddressReserve(&va, res, 0, nullptr, 0) == hipSuccess) {
-            VRegion nr;
-            nr.reserved = res;
-            hipError_t e = hipSuccess;
-            if (it != g_vr.end()) {
-                // the pool's physical chunks move to the new range: unmapped there, mapped here, no copy
-                VRegion& orr = it->second;
-                hipMemAccessDesc acc{};
-                acc.location.type = hipMemLocationTypeDevice;
-                acc.location.id = device;
-                acc.flags = hipMemAccessFlagsProtReadWrite;
-                size_t off = 0;
-                for (auto& c : orr.chunks) {
-                    if (e == hipSuccess) e = hipMemUnmap((char*)p + off, c.second);
-                    if (e == hipSuccess) e = hipMemMap((char*)va + off, c.second, 0, c.first, 0);
-                    if (e == hipSuccess) e = hipMemSetAccess((char*)va + off, c.second, &acc, 1);
-                    off += c.second;
-                }
-                if (e != hipSuccess) return bb::fail(BBH_ERR_HIP, "moving a pool's memory to a larger address range: %s", hipGetErrorString(e));
-                nr.chunks = std::move(orr.chunks);
-                nr.mapped = orr.mapped;
-                (void)hipMemAddressFree((void*)p, orr.reserved);
-                g_vr.erase(it);
-                if (want > nr.mapped) e = vr_map_more(va, nr, want - nr.mapped, device);
-                if (e != hipSuccess) { g_vr[va] = nr; p = (T*)va; return bb::fail(BBH_ERR_HIP, "growing a pool to %zu MB: %s", want >> 20, hipGetErrorString(e)); }
-                g_vr[va] = nr;
-                p = (T*)va;
-                return BBH_OK;
-            }
-            e = vr_map_more(va, nr, want, device);
-            if (e == hipSuccess) {
-                if (p && used_elems) e = hipMemcpy(va, p, used_elems * sizeof(T), hipMemcpyDeviceToDevice);
-                if (e == hipSuccess) {
-                    if (p) bb::dev_free(p);
-                    g_vr[va] = nr;
-                    p = (T*)va;
-                    return BBH_OK;
-                }
-            }
-            vr_release(va, nr);  // (fall back to the copying path below)
-            (void)hipGetLastError();
-        } else {
-            (void)hipGetLastError();
-        }
-    }
+    // (allocate, copy, free: the old pool and the new one exist side by side for the length of the copy.  Growing in place
+    // with the virtual-memory calls - hipMemAddressReserve / hipMemCreate / hipMemMap - was tried in round 4: mappings of a
+    // few KB behaved, a 2.2 GB chunk with a 1 GB chunk mapped behind it took a memory access fault on the first touch
+    // (tools/probe/vmm_probe.cpp, profiles/r04/vmm_probe.txt), so the pools stay plain allocations.)
     T* np_ = nullptr;
-    BB_HIP(bb::dev_alloc(&np_, need));
+    BB_HIP(bb::dev_alloc(&np_, new_elems * sizeof(T) + 64));  // slack: cf_load_raw over-reads 8 bytes
     if (p && used_elems) BB_HIP(hipMemcpy(np_, p, used_elems * sizeof(T), hipMemcpyDeviceToDevice));
-    if (p) pool_free((void*)p);
+    if (p) bb::dev_free(p);
     p = np_;
     return BBH_OK;
 }
@@ -2606,7 +2433,7 @@ void free_pools(bbh_tree* t) {
     TreeDev& h = t->h;
     void* ptrs[] = {h.node_cent, h.node_card, h.node_link, h.node_rm, h.node_hdr, h.scratch_cent, h.cf8, h.cf16, h.cf32};
     for (void* p : ptrs)
-        if (p) pool_free(p);
+        if (p) bb::dev_free(p);
     h.node_cent = nullptr; h.node_card = nullptr; h.node_link = nullptr; h.node_rm = nullptr; h.node_hdr = nullptr;
     h.scratch_cent = nullptr; h.cf8 = nullptr; h.cf16 = nullptr; h.cf32 = nullptr;
     h.cap_nodes = h.cap8 = h.cap16 = h.cap32 = 0;
@@ -2636,8 +2463,6 @@ int init_empty(bbh_tree* t) {
     t->chain_valid = false;
     t->pipe_ml = false;
     t->unsup_stretch = 0;
-    t->inserted = 0;
-    t->expected = 0;
     return BBH_OK;
 }
 
@@ -2732,14 +2557,6 @@ static bool dense_launch(size_t n_trees, size_t lds_bytes) {
 //   appended buffer of several members - an eighth of the elements is more than any workload measured took (S-fake 3 %,
 //   S-ecfp 1 %, S-rdkit-like 10 %); nodes: one per bf / 2 elements (a node is half full after its split); tracking cluster
 //   features (uint32): two per node split.
-// what `todo` more elements are expected to take of a pool of which the tree's `inserted` elements took `used` (15 % on top),
-// or `fallback` while the tree is too young to know its own rates
-static uint64_t by_rate(const bbh_tree* t, uint32_t used, uint64_t todo, uint64_t fallback) {
-    if (t->inserted < 16384) return fallback;
-    const double rate = (double)used / (double)t->inserted;
-    return (uint64_t)(rate * (double)todo * 1.15) + 4096;
-}
-
 int pregrow(bbh_tree* t, int64_t n, int width) {
     TreeDev& h = t->h;
     if (tiny_pools()) {
@@ -2750,11 +2567,10 @@ int pregrow(bbh_tree* t, int64_t n, int width) {
         return BBH_OK;
     }
     const uint64_t un = (uint64_t)std::max<int64_t>(n, 0);
-    const uint64_t todo = std::max<uint64_t>(un, (uint64_t)std::max<int64_t>(t->expected, 0));  // this call, or everything announced
-    if (width <= 1) BB_TRY(grow_cf(t, 0, clamp30((uint64_t)h.ctr[C_N8] + by_rate(t, h.ctr[C_N8], todo, un / 8 + 1024))));
+    if (width <= 1) BB_TRY(grow_cf(t, 0, clamp30((uint64_t)h.ctr[C_N8] + un / 8 + 1024)));
     if (width == 2) BB_TRY(grow_cf(t, 1, clamp30((uint64_t)h.ctr[C_N16] + un + 64)));
-    BB_TRY(grow_nodes(t, clamp30((uint64_t)h.ctr[C_NODES] + by_rate(t, h.ctr[C_NODES], todo, un / (uint64_t)std::max(1, h.bf / 2) + 64))));
-    BB_TRY(grow_cf(t, 2, clamp30((uint64_t)h.ctr[C_N32] + by_rate(t, h.ctr[C_N32], todo, un / (uint64_t)std::max(1, h.bf / 6) + 256))));
+    BB_TRY(grow_nodes(t, clamp30((uint64_t)h.ctr[C_NODES] + un / (uint64_t)std::max(1, h.bf / 2) + 64)));
+    BB_TRY(grow_cf(t, 2, clamp30((uint64_t)h.ctr[C_N32] + un / (uint64_t)std::max(1, h.bf / 6) + 256)));
     return BBH_OK;
 }
 
@@ -2942,8 +2758,6 @@ int run_insert_multi(std::vector<Job>& jobs, hipStream_t s) {
             {
                 const int kk = log_kernel[0] == 'p' ? 0 : (log_kernel[0] == 'f' ? 1 : 2);
                 t->kcount[kk] += (uint64_t)back.processed;
-                t->inserted += (uint64_t)back.processed;
-                t->expected = std::max<int64_t>(0, t->expected - back.processed);
                 t->kcount[3 + kk] += 1;
                 if (back.stop_reason == STOP_PIPE_UNSUPPORTED) t->kcount[6] += 1;
                 if (back.stop_reason == STOP_NODES || back.stop_reason == STOP_CF8 || back.stop_reason == STOP_CF16 || back.stop_reason == STOP_CF32) t->kcount[7] += 1;
@@ -2960,13 +2774,12 @@ int run_insert_multi(std::vector<Job>& jobs, hipStream_t s) {
                 return clamp30(std::max<uint64_t>((uint64_t)cap + cap / 2, (uint64_t)used + expect));
             };
             const uint64_t uleft = (uint64_t)std::max<int64_t>(left, 0);
-            const uint64_t todo = std::max<uint64_t>(uleft, (uint64_t)std::max<int64_t>(t->expected, 0));  // (what is left of this call, or of everything announced)
             switch (back.stop_reason) {
                 case STOP_DONE: break;
-                case STOP_NODES: rc = grow_nodes(t, more(h.ctr[C_NODES], h.cap_nodes, by_rate(t, h.ctr[C_NODES], todo, uleft / (uint64_t)std::max(1, h.bf / 2) + 64))); break;
-                case STOP_CF8: rc = grow_cf(t, 0, more(h.ctr[C_N8], h.cap8, by_rate(t, h.ctr[C_N8], todo, uleft / 8 + 1024))); break;
+                case STOP_NODES: rc = grow_nodes(t, more(h.ctr[C_NODES], h.cap_nodes, uleft / (uint64_t)std::max(1, h.bf / 2) + 64)); break;
+                case STOP_CF8: rc = grow_cf(t, 0, more(h.ctr[C_N8], h.cap8, uleft / 8 + 1024)); break;
                 case STOP_CF16: rc = grow_cf(t, 1, more(h.ctr[C_N16], h.cap16, (j.width == 2 ? uleft : uleft / 64) + 64)); break;
-                case STOP_CF32: rc = grow_cf(t, 2, more(h.ctr[C_N32], h.cap32, by_rate(t, h.ctr[C_N32], todo, uleft / (uint64_t)std::max(1, h.bf / 6) + 256))); break;
+                case STOP_CF32: rc = grow_cf(t, 2, more(h.ctr[C_N32], h.cap32, uleft / (uint64_t)std::max(1, h.bf / 6) + 256)); break;
                 case STOP_DEPTH: rc = bb::fail(BBH_ERR_CAPACITY, "tree deeper than %d levels (or corrupt link)", MAXD); break;
                 case STOP_RANGE: rc = bb::fail(BBH_ERR_INVALID, "n_samples exceeds 2^32-1 (engine limit)"); break;
                 case STOP_PIPE_UNSUPPORTED:
@@ -3462,12 +3275,6 @@ extern "C" int bbh_tree_gather_centroids(bbh_tree* t, const int64_t* positions, 
     if (!t || (m > 0 && (!positions || !out))) return bb::fail(BBH_ERR_INVALID, "null argument");
     if (m == 0) return BBH_OK;
     return gather_positions(t, positions, m, 0, nullptr, out);
-}
-
-extern "C" int bbh_tree_expect(bbh_tree* t, int64_t n_elements) {
-    if (!t || n_elements < 0) return bb::fail(BBH_ERR_INVALID, "bbh_tree_expect: null tree or negative count");
-    t->expected = n_elements;
-    return BBH_OK;
 }
 
 extern "C" int bbh_tree_kernel_counts(bbh_tree* t, uint64_t* out8) {

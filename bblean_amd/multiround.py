@@ -463,12 +463,6 @@ class _Exchange:
             slabs.append(out)
         owned = [b for b in range(len(batches)) if owner(b) == rank]
         trees = {b: make_tree() for b in owned}
-        for b in owned:  # (the tree is told how many BitFeatures are coming: its pools are then sized once, not chunk by chunk)
-            t = trees[b]
-            n_in = sum(int(ent[5]) for ent in batches[b])
-            nf = next((int(ent[6]) - 1 for ent in batches[b] if int(ent[6]) > 1), None)
-            if n_in and nf and hasattr(t, "_announce"):
-                t._announce(nf, n_in)
         members: dict[tuple[int, str], _IndexLists] = {}   # (batch, key) -> the table's member lists, once its first chunk is here
         offsets: dict[tuple[int, str], NDArray[np.int64]] = {}
         n_steps = max((len(x) for x in slabs), default=0)

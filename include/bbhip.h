@@ -198,12 +198,6 @@ int bbh_tree_gather_centroids(bbh_tree* t, const int64_t* positions, int64_t m, 
  * [3] appends, [4] splits, [5] nodes, [6] max depth, [7] BitFeature slots used */
 int bbh_tree_stats(bbh_tree* t, uint64_t* out8);
 
-/* A hint, never a limit: the caller is about to insert n_elements elements over the following fit calls (a merge round
- * knows how many BitFeatures its tables hold, multiround.py:240-312).  The tree's pools are then sized for all of them in
- * one step as soon as the tree knows its own rates, instead of growing call by call - a pool of tens of GB that grows is
- * held twice while it does. */
-int bbh_tree_expect(bbh_tree* t, int64_t n_elements);
-
 /* Which of the three insertion kernels did the work, since the handle was created (tests, bench.py):
  * [0..2] elements inserted by the pipelined / the steady-state / the complete kernel, [3..5] their launches,
  * [6] launches the pipelined kernel ended because the tree had a shape it does not handle, [7] launches that
