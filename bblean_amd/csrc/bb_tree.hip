@@ -2790,7 +2790,14 @@ int run_insert_multi(std::vector<Job>& jobs, hipStream_t s) {
                     j.old_left = t->unsup_stretch;
                     break;
                 case STOP_PIPE_NEEDS_ML: t->pipe_ml = true; break;  // relaunched at once, with the multi-level instance
-                case STOP_INTERNAL: rc = bb::fail(BBH_ERR_HIP, "pipelined kernel: a wait gave up (internal error)"); break;
+                case STOP_INTERNAL: {
+                    unsigned int line = 0;
+                    (void)hipMemcpyFromSymbol(&line, HIP_SYMBOL(g_pipe_giveup_line), sizeof(line));
+                    const unsigned int zero = 0;
+                    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_pipe_giveup_line), &zero, sizeof(zero));
+                    rc = bb::fail(BBH_ERR_HIP, "pipelined kernel: a wait gave up (internal error; first at bb_tree_pipe.inc:%u)", line);
+                    break;
+                }
                 default: rc = bb::fail(BBH_ERR_HIP, "unknown stop reason %d", back.stop_reason); break;
             }
         }
