@@ -116,6 +116,7 @@ struct TreeDev {
     unsigned long long phase[16];  // shader-clock cycles per phase (thread 0), debug; [8..] descent detail
     unsigned long long sphase[8]; // same, inside split_node
     unsigned long long mlprof[4];  // multi-level router (phase-timer build): tracking-CF cache misses, levels committed
+    unsigned long long rprof[4];   // router (phase-timer build): cycles waiting for a ring entry / wave 2's stamp / a leaf's pending jobs / a full leaf's decision
     // job of the next launch
     const uint8_t* rows;
     long long row_stride;
@@ -2459,6 +2460,7 @@ int init_empty(bbh_tree* t) {
     std::memset(h.phase, 0, sizeof(h.phase));
     std::memset(h.sphase, 0, sizeof(h.sphase));
     std::memset(h.mlprof, 0, sizeof(h.mlprof));
+    std::memset(h.rprof, 0, sizeof(h.rprof));
     h.stats[5] = 1;
     t->chain_valid = false;
     t->pipe_ml = false;
@@ -2754,6 +2756,7 @@ int run_insert_multi(std::vector<Job>& jobs, hipStream_t s) {
             std::memcpy(h.phase, back.phase, sizeof(h.phase));
             std::memcpy(h.sphase, back.sphase, sizeof(h.sphase));
             std::memcpy(h.mlprof, back.mlprof, sizeof(h.mlprof));
+            std::memcpy(h.rprof, back.rprof, sizeof(h.rprof));
             j.done += back.processed;
             {
                 const int kk = log_kernel[0] == 'p' ? 0 : (log_kernel[0] == 'f' ? 1 : 2);
@@ -3306,6 +3309,12 @@ extern "C" int bbh_tree_stats(bbh_tree* t, uint64_t* out8) {
             fprintf(stderr, " %s: %.3f/insert x %.0f cycles", kd[i], n > 0 ? (double)t->h.sphase[2 * i + 1] / n : 0.0,
                     t->h.sphase[2 * i + 1] ? (double)t->h.sphase[2 * i] / (double)t->h.sphase[2 * i + 1] : 0.0);
         fprintf(stderr, "\n");
+        fprintf(stderr, "[bbhip pipe router waits, per insert] ring entry %.0f, row + pre-compare of wave 2 %.0f, pending jobs of a nearly full leaf %.0f, "
+                "decision on a full leaf %.0f\n", n > 0 ? (double)t->h.rprof[0] / n : 0.0, n > 0 ? (double)t->h.rprof[1] / n : 0.0,
+                n > 0 ? (double)t->h.rprof[2] / n : 0.0, n > 0 ? (double)t->h.rprof[3] / n : 0.0);
+        if (t->h.mlprof[2] != 0)
+            fprintf(stderr, "[bbhip pipe mid-run splits] %.4f/insert: rendezvous %.0f cycles, split %.0f cycles each\n", n > 0 ? (double)t->h.stats[4] / n : 0.0,
+                    t->h.stats[4] ? (double)t->h.mlprof[2] / (double)t->h.stats[4] : 0.0, t->h.stats[4] ? (double)t->h.mlprof[3] / (double)t->h.stats[4] : 0.0);
         if (t->pipe_ml)
             fprintf(stderr, "[bbhip pipe multi-level router] upper-slot fills %.3f/insert x %.0f cycles; tracking levels committed %.3f/insert, "
                     "cluster-feature cache misses %.3f/insert\n", n > 0 ? (double)t->h.sphase[7] / n : 0.0,
