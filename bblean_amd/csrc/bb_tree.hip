@@ -3312,9 +3312,6 @@ extern "C" int bbh_tree_stats(bbh_tree* t, uint64_t* out8) {
         fprintf(stderr, "[bbhip pipe router waits, per insert] ring entry %.0f, row + pre-compare of wave 2 %.0f, pending jobs of a nearly full leaf %.0f, "
                 "decision on a full leaf %.0f\n", n > 0 ? (double)t->h.rprof[0] / n : 0.0, n > 0 ? (double)t->h.rprof[1] / n : 0.0,
                 n > 0 ? (double)t->h.rprof[2] / n : 0.0, n > 0 ? (double)t->h.rprof[3] / n : 0.0);
-        if (t->h.mlprof[2] != 0)
-            fprintf(stderr, "[bbhip pipe mid-run splits] %.4f/insert: rendezvous %.0f cycles, split %.0f cycles each\n", n > 0 ? (double)t->h.stats[4] / n : 0.0,
-                    t->h.stats[4] ? (double)t->h.mlprof[2] / (double)t->h.stats[4] : 0.0, t->h.stats[4] ? (double)t->h.mlprof[3] / (double)t->h.stats[4] : 0.0);
         if (t->pipe_ml)
             fprintf(stderr, "[bbhip pipe multi-level router] upper-slot fills %.3f/insert x %.0f cycles; tracking levels committed %.3f/insert, "
                     "cluster-feature cache misses %.3f/insert\n", n > 0 ? (double)t->h.sphase[7] / n : 0.0,
