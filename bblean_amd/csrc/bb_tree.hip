@@ -645,13 +645,18 @@ __device__ __forceinline__ Cand node_best(const KCt& k, int& cmp_par, uint32_t n
                         br = take ? r : br;
                     }
                 };
+                // (only the node's `len` rows are walked, not all bf + 1: the length arrives with the first block - until round 4
+                // a half-full node of a bf 1000 tree cost what a full one does)
                 issue(dA, lkA, 0);
-                for (; r_start < rows; r_start += 2 * BLK) {
+                uint32_t lim = rows;
+                for (; r_start < lim; r_start += 2 * BLK) {
                     issue(dB, lkB, r_start + BLK);
                     consume(dA, lkA, r_start);
+                    if (r_start == 0) lim = len < rows ? len : rows;
                     issue(dA, lkA, r_start + 2 * BLK);
-                    if (r_start + BLK < rows) consume(dB, lkB, r_start + BLK);
+                    if (r_start + BLK < lim) consume(dB, lkB, r_start + BLK);
                 }
+                r_start = rows;  // (every row below `len` has been looked at)
             }
         }
         for (uint32_t r0 = r_start; r0 < rows; r0 += 64) {
