@@ -3319,9 +3319,10 @@ extern "C" int bbh_tree_stats(bbh_tree* t, uint64_t* out8) {
                 n > 0 ? (double)t->h.rprof[2] / n : 0.0, n > 0 ? (double)t->h.rprof[3] / n : 0.0);
         if (t->pipe_ml)
             fprintf(stderr, "[bbhip pipe multi-level router] upper-slot fills %.3f/insert x %.0f cycles; tracking levels committed %.3f/insert, "
-                    "cluster-feature cache misses %.3f/insert\n", n > 0 ? (double)t->h.sphase[7] / n : 0.0,
+                    "cluster-feature cache misses %.3f/insert; router waiting for a level's update by a helper wave %.0f cycles/insert, for "
+                    "all of them and their stores (before a fill) %.0f\n", n > 0 ? (double)t->h.sphase[7] / n : 0.0,
                     t->h.sphase[7] ? (double)t->h.sphase[6] / (double)t->h.sphase[7] : 0.0, n > 0 ? (double)t->h.mlprof[1] / n : 0.0,
-                    n > 0 ? (double)t->h.mlprof[0] / n : 0.0);
+                    n > 0 ? (double)t->h.mlprof[0] / n : 0.0, n > 0 ? (double)t->h.mlprof[2] / n : 0.0, n > 0 ? (double)t->h.mlprof[3] / n : 0.0);
     }
     if (getenv("BBHIP_PHASES")) {
         fprintf(stderr, "[bbhip phases, cycles/insert]");
