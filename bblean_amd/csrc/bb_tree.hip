@@ -115,7 +115,7 @@ struct TreeDev {
     unsigned long long stats[8];
     unsigned long long phase[16];  // shader-clock cycles per phase (thread 0), debug; [8..] descent detail
     unsigned long long sphase[8]; // same, inside split_node
-    unsigned long long mlprof[4];  // multi-level router (phase-timer build): tracking-CF cache misses, levels committed
+    unsigned long long mlprof[8];  // multi-level router (phase-timer build): tracking-CF cache misses, levels committed
     unsigned long long rprof[4];   // router (phase-timer build): cycles waiting for a ring entry / wave 2's stamp / a leaf's pending jobs / a full leaf's decision
     // job of the next launch
     const uint8_t* rows;
@@ -3320,9 +3320,10 @@ extern "C" int bbh_tree_stats(bbh_tree* t, uint64_t* out8) {
         if (t->pipe_ml)
             fprintf(stderr, "[bbhip pipe multi-level router] upper-slot fills %.3f/insert x %.0f cycles; tracking levels committed %.3f/insert, "
                     "cluster-feature cache misses %.3f/insert; router waiting for a level's update by a helper wave %.0f cycles/insert, for "
-                    "all of them and their stores (before a fill) %.0f\n", n > 0 ? (double)t->h.sphase[7] / n : 0.0,
+                    "all of them and their stores (before a fill) %.0f; of a fill: loads %.0f cycles, slot + corrections %.0f\n", n > 0 ? (double)t->h.sphase[7] / n : 0.0,
                     t->h.sphase[7] ? (double)t->h.sphase[6] / (double)t->h.sphase[7] : 0.0, n > 0 ? (double)t->h.mlprof[1] / n : 0.0,
-                    n > 0 ? (double)t->h.mlprof[0] / n : 0.0, n > 0 ? (double)t->h.mlprof[2] / n : 0.0, n > 0 ? (double)t->h.mlprof[3] / n : 0.0);
+                    n > 0 ? (double)t->h.mlprof[0] / n : 0.0, n > 0 ? (double)t->h.mlprof[2] / n : 0.0, n > 0 ? (double)t->h.mlprof[3] / n : 0.0,
+                    t->h.sphase[7] ? (double)t->h.mlprof[4] / (double)t->h.sphase[7] : 0.0, t->h.sphase[7] ? (double)t->h.mlprof[5] / (double)t->h.sphase[7] : 0.0);
     }
     if (getenv("BBHIP_PHASES")) {
         fprintf(stderr, "[bbhip phases, cycles/insert]");
