@@ -2611,7 +2611,17 @@ int run_insert_multi(std::vector<Job>& jobs, hipStream_t s) {
         j.t->chain_valid = false;
         lds = std::max(lds, j.t->lds);
     }
+    // Several trees in the pipelined kernel (bf 254, where it is well ahead of the steady-state kernel: 8 x 1 M rows S-fake 1.85 M
+    // against 1.46 M fingerprints/s, S-ecfp 1.53 M against 1.18 M; at bf 50 eight steady-state workgroups are as fast as eight
+    // pipelines that leave for the multi-level instance): worth it while the trees stay in it.  Trees that keep leaving it
+    // (shapes it hands over every few ten thousand elements: S-rdkit-like rows at bf 254) wait for the others' workgroups after
+    // every stop and take everybody to the steady-state kernel for their stretch - measured 0.69 M fingerprints/s against
+    // 1.33 M with the steady-state kernel alone.  So: a shared launch that a quarter of its trees left midway for an
+    // unsupported shape ends the attempt for this call.
+    bool multi_pipe_ok = true;
+    long long multi_chunk = 1ll << 15;  // elements per tree and shared launch: doubles (to 2^18) with every launch no tree left midway
     while (rc == BBH_OK) {
+        long long multi_requested = 0;
         active.clear();
         for (size_t i = 0; i < jobs.size(); ++i)
             if (jobs[i].done < jobs[i].n) active.push_back(i);
@@ -2674,33 +2684,72 @@ int run_insert_multi(std::vector<Job>& jobs, hipStream_t s) {
                 for (const FastKernel& c : kFastKernels)
                     if (fk == nullptr && c.bf == (all50 ? 50 : 254) && c.buffers == f_buffers && (c.crit == -1 || c.crit == f_crit)) fk = &c;
             const dim3 grid((unsigned)active.size()), block(TB);
-            // the pipelined kernel: one tree, packed rows, the criteria of the standard pipelines
+            // The pipelined kernel: packed rows, the criteria of the standard pipelines.  Several trees (multiround shards,
+            // one workgroup each): all of them must be ready for it - a tree that is on a stretch of the steady-state
+            // kernel (old_left) takes the whole launch there, the others come along for the length of that stretch - and
+            // a launch inserts at most `multi_chunk` elements per tree: a tree that stops early (a shape the pipeline
+            // hands over, a pool that ran out) waits for the others' workgroups, and no longer than that.
             static const bool no_pipe = getenv("BBHIP_NO_PIPE") != nullptr;
+            static const bool no_pipe_multi = getenv("BBHIP_NO_PIPE_MULTI") != nullptr;
+            const long long PIPE_MULTI_CHUNK = multi_chunk;
             const PipeKernel* pk = nullptr;
-            if (fk != nullptr && !no_pipe && !prof_phases && single && f_packed && jobs[active[0]].old_left == 0 &&
-                harr[0].n_elems < (1ll << 31)) {
-                const int want_ml = jobs[active[0]].t->pipe_ml ? 1 : 0;
-                for (const PipeKernel& c : kPipeKernels)
-                    if (pk == nullptr && c.bf == (all50 ? 50 : 254) && c.crit == f_crit && c.ml == want_ml) pk = &c;
+            const bool pipe_possible = fk != nullptr && !no_pipe && !prof_phases && f_packed && (single || (all254 && !no_pipe_multi && multi_pipe_ok));
+            bool recopy = false;
+            if (pipe_possible) {
+                bool all_ready = true;
+                int want_ml = 0;
+                int64_t max_old = 0;
+                for (size_t a = 0; a < active.size(); ++a) {
+                    const Job& pj = jobs[active[a]];
+                    all_ready = all_ready && pj.old_left == 0 && harr[a].n_elems < (1ll << 31);
+                    max_old = std::max(max_old, pj.old_left);
+                    want_ml |= pj.t->pipe_ml ? 1 : 0;  // (the multi-level instance also runs trees of one exact level)
+                }
+                if (all_ready) {
+                    for (const PipeKernel& c : kPipeKernels)
+                        if (pk == nullptr && c.bf == (all50 ? 50 : 254) && c.crit == f_crit && c.ml == want_ml) pk = &c;
+                    if (pk != nullptr && !single)
+                        for (size_t a = 0; a < active.size(); ++a) {
+                            if (harr[a].n_elems > PIPE_MULTI_CHUNK) { harr[a].n_elems = PIPE_MULTI_CHUNK; recopy = true; }
+                            multi_requested += harr[a].n_elems;
+                        }
+                } else if (!single && max_old > 0) {
+                    for (size_t a = 0; a < active.size(); ++a)
+                        if (jobs[active[a]].old_left == 0 && harr[a].n_elems > max_old) { harr[a].n_elems = max_old; recopy = true; }
+                }
+            }
+            if (!pipe_possible && !single) {
+                // (the attempt is over: nobody comes back to the pipeline, the stretches are the rest of the input)
+                for (size_t a = 0; a < active.size(); ++a) {
+                    Job& oj = jobs[active[a]];
+                    if (oj.old_left > 0) { oj.old_left = 0; harr[a].n_elems = oj.n - oj.done; recopy = true; }
+                }
             }
             if (pk != nullptr) {
                 // tier promotions of elements in flight take cf16 / cf32 slots without asking: keep a reserve
-                bbh_tree* t0 = jobs[active[0]].t;
-                bool grown = false;
-                if (t0->h.cap16 - std::min(t0->h.cap16, t0->h.ctr[C_N16]) < (uint32_t)PROMO_RESERVE) {
-                    rc = grow_cf(t0, 1, clamp30((uint64_t)t0->h.ctr[C_N16] + 2 * PROMO_RESERVE));
-                    grown = true;
-                }
-                if (rc == BBH_OK && t0->h.cap32 - std::min(t0->h.cap32, t0->h.ctr[C_N32]) < (uint32_t)PROMO_RESERVE) {
-                    rc = grow_cf(t0, 2, clamp30((uint64_t)t0->h.ctr[C_N32] + 2 * PROMO_RESERVE));
-                    grown = true;
+                for (size_t a = 0; a < active.size() && rc == BBH_OK; ++a) {
+                    bbh_tree* ta = jobs[active[a]].t;
+                    bool grown = false;
+                    if (ta->h.cap16 - std::min(ta->h.cap16, ta->h.ctr[C_N16]) < (uint32_t)PROMO_RESERVE) {
+                        rc = grow_cf(ta, 1, clamp30((uint64_t)ta->h.ctr[C_N16] + 2 * PROMO_RESERVE));
+                        grown = true;
+                    }
+                    if (rc == BBH_OK && ta->h.cap32 - std::min(ta->h.cap32, ta->h.ctr[C_N32]) < (uint32_t)PROMO_RESERVE) {
+                        rc = grow_cf(ta, 2, clamp30((uint64_t)ta->h.ctr[C_N32] + 2 * PROMO_RESERVE));
+                        grown = true;
+                    }
+                    if (grown) {
+                        harr[a].cf16 = ta->h.cf16; harr[a].cf32 = ta->h.cf32; harr[a].cap16 = ta->h.cap16; harr[a].cap32 = ta->h.cap32;
+                        recopy = true;
+                    }
                 }
                 if (rc != BBH_OK) break;
-                if (grown) {
-                    harr[0].cf16 = t0->h.cf16; harr[0].cf32 = t0->h.cf32; harr[0].cap16 = t0->h.cap16; harr[0].cap32 = t0->h.cap32;
-                    e = hipMemcpyAsync(dptr, harr.data(), sizeof(TreeDev), hipMemcpyHostToDevice, s);
-                    if (e != hipSuccess) { rc = bb::fail(BBH_ERR_HIP, "H2D: %s", hipGetErrorString(e)); break; }
-                }
+            }
+            if (recopy) {
+                e = hipMemcpyAsync(dptr, harr.data(), active.size() * sizeof(TreeDev), hipMemcpyHostToDevice, s);
+                if (e != hipSuccess) { rc = bb::fail(BBH_ERR_HIP, "H2D: %s", hipGetErrorString(e)); break; }
+            }
+            if (pk != nullptr) {
                 log_kernel = "pipe";
                 static const bool pipe_phases = getenv("BBHIP_PIPE_PHASES") != nullptr;
                 if (pipe_phases && pk->crit == BBH_CRIT_DIAMETER && pk->bf == 50 && pk->ml)
@@ -2750,6 +2799,12 @@ int run_insert_multi(std::vector<Job>& jobs, hipStream_t s) {
                     (unsigned long long)(after[1] - log_before[1]), (unsigned long long)(after[2] - log_before[2]),
                     (unsigned long long)(after[3] - log_before[3]), (unsigned long long)(after[4] - log_before[4]),
                     (unsigned long long)(after[5] - log_before[5]), harr[0].stop_reason);
+        }
+        if (multi_requested > 0) {
+            size_t left_midway = 0;
+            for (size_t a = 0; a < active.size(); ++a) left_midway += harr[a].stop_reason == STOP_PIPE_UNSUPPORTED && harr[a].processed > 0;
+            if (4 * left_midway >= active.size()) multi_pipe_ok = false;
+            else if (left_midway == 0) multi_chunk = std::min<long long>(2 * multi_chunk, 1ll << 18);
         }
         for (size_t a = 0; a < active.size() && rc == BBH_OK; ++a) {
             Job& j = jobs[active[a]];

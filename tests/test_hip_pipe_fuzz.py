@@ -160,3 +160,41 @@ def test_pipe_fuzz_reaches_the_pipeline():
         t = BitBirch(branching_factor=bf, threshold=thr, merge_criterion=crit, tolerance=tol).fit(_rows(rng, n))
         done += t._engine.kernel_counts()[:3].astype(np.int64)
     assert done[0] > done[1] + done[2], done.tolist()
+
+
+@pytest.mark.parametrize("bf,tiny", [(50, False), (254, False), (254, True)])
+def test_pipe_concurrent_trees_vs_oracle(bf, tiny):
+    r"""`fit_concurrently` (multiround's first round: one workgroup per shard tree in shared launches) with shards large enough
+    for the pipelined kernel: five trees of different sizes and kinds of rows - one of them with informative internal
+    levels - leave and re-enter the pipeline at different elements (stretches of the steady-state kernel, pools that run
+    out; bf 254: the trees share launches of the pipelined kernel of 2^15 .. 2^18 elements per tree, until a quarter of them
+    leave one midway).  Every tree: the oracle's single-tree fit, element by element."""
+    from bblean_amd import fit_concurrently
+
+    rng = np.random.default_rng(4242 + bf)
+    sizes = [30_000, 12_000, 300_000 if not tiny else 40_000, 9_000, 45_000]
+    kinds = [0, 4, 4, 2, 1]
+    shards = [np.ascontiguousarray(_segment(rng, m, k)) for m, k in zip(sizes, kinds)]
+    kw = dict(branching_factor=bf, threshold=0.45, merge_criterion="diameter")
+    old = os.environ.get("BBHIP_TINY_POOLS")
+    try:
+        if tiny:
+            os.environ["BBHIP_TINY_POOLS"] = "1"
+        hips = [BitBirch(**kw) for _ in shards]
+        fit_concurrently(hips, shards)
+    finally:
+        if old is None:
+            os.environ.pop("BBHIP_TINY_POOLS", None)
+        else:
+            os.environ["BBHIP_TINY_POOLS"] = old
+    piped = 0
+    for hip, rows in zip(hips, shards):
+        ora = BitBirch(_engine_factory=OracleEngine, **kw).fit(rows)
+        assert (hip._log_leaf[-1] == ora._log_leaf[-1]).all()
+        assert hip._engine.stats()[:7].tolist() == ora._engine.stats()[:7].tolist()
+        _same_tables(hip, ora)
+        kc = hip._engine.kernel_counts()
+        assert int(kc[:3].sum()) == rows.shape[0]
+        piped += int(kc[0])
+    if bf == 254:  # (shared launches of the pipelined kernel: bf 254 only - at bf 50 eight steady-state workgroups are as fast)
+        assert piped > sum(sizes) // 4, piped
