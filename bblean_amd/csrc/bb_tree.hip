@@ -2853,6 +2853,7 @@ int run_insert_multi(std::vector<Job>& jobs, hipStream_t s) {
                     j.old_left = t->unsup_stretch;
                     break;
                 case STOP_PIPE_NEEDS_ML: t->pipe_ml = true; break;  // relaunched at once, with the multi-level instance
+                case STOP_PIPE_PREFERS_SL: t->pipe_ml = false; break;  // ... and back (after a stint of >= PIPE_ML_STINT elements)
                 case STOP_INTERNAL: {
                     unsigned int line = 0;
                     (void)hipMemcpyFromSymbol(&line, HIP_SYMBOL(g_pipe_giveup_line), sizeof(line));

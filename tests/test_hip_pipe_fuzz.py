@@ -198,3 +198,23 @@ def test_pipe_concurrent_trees_vs_oracle(bf, tiny):
         piped += int(kc[0])
     if bf == 254:  # (shared launches of the pipelined kernel: bf 254 only - at bf 50 eight steady-state workgroups are as fast)
         assert piped > sum(sizes) // 4, piped
+
+
+def test_pipe_moves_between_single_and_multi_level_instances():
+    r"""S-fake rows at bf 50: informative levels above the leaf-parents come and go (a tracking row of a freshly split node has
+    few members, its majority centroid is not all-zero yet).  The single-level instance hands the tree to the multi-level one
+    when it meets such a level (STOP_PIPE_NEEDS_ML), the multi-level one hands it back after a stint of >= 2 048 elements when
+    the shape allows (STOP_PIPE_PREFERS_SL) - every element as in the oracle's sequential fit, whichever instance inserted it."""
+    import torch
+    from bench import WORKLOADS
+
+    gen, thr, _ = WORKLOADS["fake"]
+    rows = gen(400_000, 5001, torch.device("cuda"))
+    kw = dict(branching_factor=50, threshold=thr, merge_criterion="diameter")
+    hip = BitBirch(**kw).fit(rows)
+    ora = BitBirch(_engine_factory=OracleEngine, **kw).fit(rows.cpu().numpy())
+    assert (hip._log_leaf[-1] == ora._log_leaf[-1]).all()
+    assert hip._engine.stats()[:7].tolist() == ora._engine.stats()[:7].tolist()
+    _same_tables(hip, ora)
+    kc = hip._engine.kernel_counts()
+    assert int(kc[0]) >= 390_000 and int(kc[3]) >= 4, kc.tolist()  # the pipelined kernel, in several launches (the hand-overs)
