@@ -203,7 +203,7 @@ def test_pipe_concurrent_trees_vs_oracle(bf, tiny):
 def test_pipe_moves_between_single_and_multi_level_instances():
     r"""S-fake rows at bf 50: informative levels above the leaf-parents come and go (a tracking row of a freshly split node has
     few members, its majority centroid is not all-zero yet).  The single-level instance hands the tree to the multi-level one
-    when it meets such a level (STOP_PIPE_NEEDS_ML), the multi-level one hands it back after a stint of >= 2 048 elements when
+    when it meets such a level (STOP_PIPE_NEEDS_ML), the multi-level one hands it back after a stint of >= 256 elements when
     the shape allows (STOP_PIPE_PREFERS_SL) - every element as in the oracle's sequential fit, whichever instance inserted it."""
     import torch
     from bench import WORKLOADS
