@@ -2848,8 +2848,11 @@ int run_insert_multi(std::vector<Job>& jobs, hipStream_t s) {
                 case STOP_PIPE_UNSUPPORTED:
                     // a stretch on the steady-state kernel, then the pipeline again.  A tree that keeps its unsupported shape
                     // would pay a launch that inserts nothing after every stretch: the stretch doubles (up to 4 M elements)
-                    // while the pipeline makes no progress and starts again at 8 192 as soon as it does
-                    t->unsup_stretch = back.processed > 0 || t->unsup_stretch == 0 ? 8192 : std::min<int64_t>(t->unsup_stretch * 2, 1ll << 22);
+                    // while the pipeline makes no progress and starts again at 1 024 as soon as it does
+                    // (a tree that has been in the pipeline: informative levels above the leaf-parents are mostly short-lived
+                    // there - a freshly split node's tracking row - so the first stretch is short; a new tree needs its first
+                    // 8 192 elements to get the shape at all)
+                    t->unsup_stretch = t->unsup_stretch == 0 ? 8192 : (back.processed > 0 ? 1024 : std::min<int64_t>(t->unsup_stretch * 2, 1ll << 22));
                     j.old_left = t->unsup_stretch;
                     break;
                 case STOP_PIPE_NEEDS_ML: t->pipe_ml = true; break;  // relaunched at once, with the multi-level instance

@@ -567,6 +567,21 @@ def single_gpu(args: argparse.Namespace) -> None:
                                               "unsupported_shape_stops": int(wk[6]), "stats": [int(v) for v in wt._engine.stats()[:7]]}
                 del wt
             del wf
+        # the headline workload drawn with other seeds: informative levels above the leaf-parents come and go,
+        # the tree then moves between the two instances of the pipelined kernel - the headline's seed never does in 1 M rows
+        if args.workload == "fake":
+            seeds = {}
+            for sd in (5000, 5001, 123456):
+                wf = WORKLOADS["fake"][0](n, sd, dev)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                wt = BitBirch(branching_factor=args.bf, threshold=args.threshold, merge_criterion="diameter", device=local_rank).fit(wf)
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t1
+                wk = wt._engine.kernel_counts()
+                seeds[str(sd)] = {"fingerprints_per_s": n / dt, "pipelined_kernel_launches": int(wk[3])}
+                del wt, wf
+            others["headline_other_seeds"] = seeds
 
     # BASELINE configs[2] in one run: S-ecfp, 10 M rows, the CLI's branching factor 254, `bb run --refine-num 1`
     # (fit -> set_merge(tolerance-diameter, 0.05) -> refine_inplace(n_largest=1) -> labels; cli.py:1067-1092)
