@@ -115,6 +115,7 @@ struct TreeDev {
     unsigned long long stats[8];
     unsigned long long phase[16];  // shader-clock cycles per phase (thread 0), debug; [8..] descent detail
     unsigned long long sphase[8]; // same, inside split_node
+    unsigned long long splitprof[10];  // pipelined kernel (phase-timer build): the leaf split's phases (split_node's SPH marks), splits, cycles
     unsigned long long mlprof[8];  // multi-level router (phase-timer build): tracking-CF cache misses, levels committed
     unsigned long long rprof[4];   // router (phase-timer build): cycles waiting for a ring entry / wave 2's stamp / a leaf's pending jobs / a full leaf's decision
     // job of the next launch
@@ -2464,6 +2465,7 @@ int init_empty(bbh_tree* t) {
     std::memset(h.stats, 0, sizeof(h.stats));
     std::memset(h.phase, 0, sizeof(h.phase));
     std::memset(h.sphase, 0, sizeof(h.sphase));
+    std::memset(h.splitprof, 0, sizeof(h.splitprof));
     std::memset(h.mlprof, 0, sizeof(h.mlprof));
     std::memset(h.rprof, 0, sizeof(h.rprof));
     h.stats[5] = 1;
@@ -2815,6 +2817,7 @@ int run_insert_multi(std::vector<Job>& jobs, hipStream_t s) {
             std::memcpy(h.stats, back.stats, sizeof(h.stats));
             std::memcpy(h.phase, back.phase, sizeof(h.phase));
             std::memcpy(h.sphase, back.sphase, sizeof(h.sphase));
+            std::memcpy(h.splitprof, back.splitprof, sizeof(h.splitprof));
             std::memcpy(h.mlprof, back.mlprof, sizeof(h.mlprof));
             std::memcpy(h.rprof, back.rprof, sizeof(h.rprof));
             j.done += back.processed;
@@ -3376,6 +3379,12 @@ extern "C" int bbh_tree_stats(bbh_tree* t, uint64_t* out8) {
         fprintf(stderr, "[bbhip pipe router waits, per insert] ring entry %.0f, row + pre-compare of wave 2 %.0f, pending jobs of a nearly full leaf %.0f, "
                 "decision on a full leaf %.0f\n", n > 0 ? (double)t->h.rprof[0] / n : 0.0, n > 0 ? (double)t->h.rprof[1] / n : 0.0,
                 n > 0 ? (double)t->h.rprof[2] / n : 0.0, n > 0 ? (double)t->h.rprof[3] / n : 0.0);
+        if (t->h.splitprof[8]) {
+            const double ns = (double)t->h.splitprof[8];
+            fprintf(stderr, "[bbhip pipe leaf splits] %.4f/insert x %.0f cycles:", n > 0 ? ns / n : 0.0, (double)t->h.splitprof[9] / ns);
+            for (int i = 0; i < 8; ++i) fprintf(stderr, " s%d=%.0f", i, (double)t->h.splitprof[i] / ns);
+            fprintf(stderr, "\n");
+        }
         if (t->pipe_ml)
             fprintf(stderr, "[bbhip pipe multi-level router] upper-slot fills %.3f/insert x %.0f cycles; tracking levels committed %.3f/insert, "
                     "cluster-feature cache misses %.3f/insert; router waiting for a level's update by a helper wave %.0f cycles/insert, for "
