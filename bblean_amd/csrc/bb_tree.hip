@@ -2618,9 +2618,10 @@ int run_insert_multi(std::vector<Job>& jobs, hipStream_t s) {
     // pipelines that leave for the multi-level instance): worth it while the trees stay in it.  Trees that keep leaving it
     // (shapes it hands over every few ten thousand elements: S-rdkit-like rows at bf 254) wait for the others' workgroups after
     // every stop and take everybody to the steady-state kernel for their stretch - measured 0.69 M fingerprints/s against
-    // 1.33 M with the steady-state kernel alone.  So: a shared launch that a quarter of its trees left midway for an
-    // unsupported shape ends the attempt for this call.
+    // 1.33 M with the steady-state kernel alone.  So: when a quarter of the call's trees have left shared launches midway
+    // for an unsupported shape, the attempt is over for this call.
     bool multi_pipe_ok = true;
+    size_t multi_left_midway = 0;  // trees that left a shared launch midway for an unsupported shape, over the whole call
     long long multi_chunk = 1ll << 15;  // elements per tree and shared launch: doubles (to 2^18) with every launch no tree left midway
     while (rc == BBH_OK) {
         long long multi_requested = 0;
@@ -2805,7 +2806,8 @@ int run_insert_multi(std::vector<Job>& jobs, hipStream_t s) {
         if (multi_requested > 0) {
             size_t left_midway = 0;
             for (size_t a = 0; a < active.size(); ++a) left_midway += harr[a].stop_reason == STOP_PIPE_UNSUPPORTED && harr[a].processed > 0;
-            if (4 * left_midway >= active.size()) multi_pipe_ok = false;
+            multi_left_midway += left_midway;
+            if (4 * multi_left_midway >= jobs.size()) multi_pipe_ok = false;
             else if (left_midway == 0) multi_chunk = std::min<long long>(2 * multi_chunk, 1ll << 18);
         }
         for (size_t a = 0; a < active.size() && rc == BBH_OK; ++a) {
