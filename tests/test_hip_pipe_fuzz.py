@@ -89,7 +89,16 @@ def _same_tables(a: BitBirch, b: BitBirch) -> None:
         assert (ma[k].counts == mo[k].counts).all() and (ma[k].flat == mo[k].flat).all()
 
 
-@pytest.mark.parametrize("seed", range(36))
+def _seed_range() -> range:
+    r"""36 seeds by default; `BB_FUZZ_SEEDS=lo:hi` runs another range (soak runs after changes to the pipelined kernel)."""
+    spec = os.environ.get("BB_FUZZ_SEEDS", "")
+    if ":" in spec:
+        lo, hi = spec.split(":")
+        return range(int(lo), int(hi))
+    return range(36)
+
+
+@pytest.mark.parametrize("seed", _seed_range())
 def test_pipe_fuzz_vs_oracle(seed):
     rng = np.random.default_rng(7000 + seed)
     bf = 50 if seed % 3 else 254
