@@ -129,6 +129,7 @@ struct TreeDev {
     // result of the last launch
     long long processed;
     int32_t stop_reason;
+    int32_t audit;  // (phase-timer build of the pipelined kernel, BBHIP_PIPE_AUDIT=1) compare the LDS state with HBM at every run end
 };
 
 // LDS layout: byte offsets from the start of the dynamic shared segment
@@ -2754,7 +2755,14 @@ int run_insert_multi(std::vector<Job>& jobs, hipStream_t s) {
             }
             if (pk != nullptr) {
                 log_kernel = "pipe";
-                static const bool pipe_phases = getenv("BBHIP_PIPE_PHASES") != nullptr;
+                static const bool pipe_audit = getenv("BBHIP_PIPE_AUDIT") != nullptr;
+                static const bool pipe_phases = getenv("BBHIP_PIPE_PHASES") != nullptr || pipe_audit;
+                if (pipe_audit) {
+                    static const int audit_mode = std::strcmp(getenv("BBHIP_PIPE_AUDIT"), "corrupt") == 0 ? 2 : 1;
+                    for (size_t a = 0; a < active.size(); ++a) harr[a].audit = audit_mode;
+                    e = hipMemcpyAsync(dptr, harr.data(), active.size() * sizeof(TreeDev), hipMemcpyHostToDevice, s);
+                    if (e != hipSuccess) { rc = bb::fail(BBH_ERR_HIP, "H2D: %s", hipGetErrorString(e)); break; }
+                }
                 if (pipe_phases && pk->crit == BBH_CRIT_DIAMETER && pk->bf == 50 && pk->ml)
                     hipLaunchKernelGGL((k_tree_pipe<KP<50, BBH_CRIT_DIAMETER, 1>, true>), grid, block, pk->lds, s, dptr);
                 else if (pipe_phases && pk->crit == BBH_CRIT_DIAMETER && pk->bf == 50)
@@ -2787,6 +2795,16 @@ int run_insert_multi(std::vector<Job>& jobs, hipStream_t s) {
         if (e == hipSuccess) e = hipMemcpyAsync(harr.data(), dptr, active.size() * sizeof(TreeDev), hipMemcpyDeviceToHost, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);
         if (e != hipSuccess) { rc = bb::fail(BBH_ERR_HIP, "tree_insert: %s", hipGetErrorString(e)); break; }
+        if (log_kernel[0] == 'p' && harr[0].audit) {
+            unsigned int au = 0;
+            (void)hipMemcpyFromSymbol(&au, HIP_SYMBOL(g_pipe_audit), sizeof(au));
+            if (au != 0) {
+                const unsigned int zero = 0;
+                (void)hipMemcpyToSymbol(HIP_SYMBOL(g_pipe_audit), &zero, sizeof(zero));
+                rc = bb::fail(BBH_ERR_HIP, "pipelined kernel, run-end audit: LDS state differs from HBM (check %u at bb_tree_pipe.inc:%u)", au >> 16, au & 0xFFFFu);
+                break;
+            }
+        }
         if (launch_log) {
             const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - log_t0).count();
             uint64_t after[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -3366,6 +3384,11 @@ extern "C" int bbh_tree_stats(bbh_tree* t, uint64_t* out8) {
     if (!t || !out8) return bb::fail(BBH_ERR_INVALID, "null argument");
     for (int i = 0; i < 7; ++i) out8[i] = t->h.stats[i];
     out8[7] = t->h.ctr[C_IDS];
+    if (getenv("BBHIP_PIPE_AUDIT")) {
+        unsigned long long runs = 0;
+        (void)hipMemcpyFromSymbol(&runs, HIP_SYMBOL(g_pipe_audit_runs), sizeof(runs));
+        fprintf(stderr, "[bbhip pipe audit] %llu slots audited at run ends so far (this process), no difference\n", runs);
+    }
     if (getenv("BBHIP_PIPE_PHASES")) {
         static const char* nm[16] = {"router:setup", "router:wait", "router:compare", "router:commit", "router:drain", "leaf:wait", "leaf:fill",
                                      "leaf:compare", "leaf:cf+dot", "leaf:decide+apply", "all:flush", "all:cold", "#runs", "#router-stale", "#leaf-pre-hits", "#leaf-stale"};

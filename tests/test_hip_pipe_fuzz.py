@@ -227,3 +227,36 @@ def test_pipe_moves_between_single_and_multi_level_instances():
     _same_tables(hip, ora)
     kc = hip._engine.kernel_counts()
     assert int(kc[0]) >= 390_000 and int(kc[3]) >= 4, kc.tolist()  # the pipelined kernel, in several launches (the hand-overs)
+
+
+def test_pipe_run_end_audit():
+    r"""The audit build of the pipelined kernel (`BBHIP_PIPE_AUDIT=1`: the phase-timer instances - diameter criterion - compare,
+    whenever a run has drained, what the router holds about its tracking nodes (rows, popcounts, n, child ids, the children's
+    lengths, nothing pending) and what the leaf engine holds about the leaves in its slots (rows, popcounts, row records,
+    length) with HBM: every change is written through, so they must agree) over all workloads at bf 50 / 254, with pools
+    that run out, element by element against the oracle as well.  The switch is read once per process: a subprocess.  And the
+    audit audited: with `BBHIP_PIPE_AUDIT=corrupt` one bit of the router's slot is flipped before the comparison - the fit
+    must fail with the audit's message."""
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    env = dict(os.environ, BBHIP_PIPE_AUDIT="1", BBHIP_TINY_POOLS="1")
+    env.pop("BBHIP_LAUNCH_LOG", None)
+    r = subprocess.run([sys.executable, str(root / "tools" / "pipe_check.py"), "30000", "50", "254"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "ALL OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    env.pop("BBHIP_TINY_POOLS")
+    r = subprocess.run([sys.executable, str(root / "tools" / "pipe_check.py"), "60000", "50", "254"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "ALL OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import torch\nfrom bench import WORKLOADS\nfrom bblean_amd import BitBirch\n"
+            "fps = WORKLOADS['fake'][0](40000, 5, torch.device('cuda'))\n"
+            "t = BitBirch(branching_factor=50, threshold=0.3, merge_criterion='diameter').fit(fps)\n"
+            "t._engine.stats()\n" % (str(root), str(root / "tests")))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stderr.splitlines() if "[bbhip pipe audit]" in ln]
+    assert line and int(line[-1].split()[3]) > 100, r.stderr[-2000:]  # hundreds of runs ended and were audited
+    r = subprocess.run([sys.executable, "-c", code], env=dict(env, BBHIP_PIPE_AUDIT="corrupt"), capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "run-end audit" in r.stderr, r.stderr[-2000:]
