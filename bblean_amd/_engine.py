@@ -374,6 +374,18 @@ class HipEngine:
         _lib.check(self._lib.bbh_tree_kernel_counts(self._h, out.ctypes.data))
         return out
 
+    def memory(self) -> NDArray[np.uint64]:
+        r"""[0] node pools (bytes, capacity), [1] their used part, [2] cluster-feature pools, [3] peak of this tree's
+        allocations, [4] compactions of the node pools, [5] / [6] nodes the last one sealed / left at full capacity,
+        [7] sealed nodes thawed by an insertion."""
+        out = np.zeros(8, dtype=np.uint64)
+        _lib.check(self._lib.bbh_tree_memory(self._h, out.ctypes.data))
+        return out
+
+    def compact(self, seal: bool = True) -> None:
+        r"""Compact the node pools now (tests; the engine does it on its own when large pools have to grow)."""
+        _lib.check(self._lib.bbh_tree_compact(self._h, 1 if seal else 0))
+
     def close(self) -> None:
         if getattr(self, "_h", None) is not None and self._h.value:
             self._lib.bbh_tree_destroy(self._h)

@@ -61,6 +61,8 @@ _PROTOTYPES = {
     "bbh_tree_gather_centroids": (_int, [_vp, _vp, _i64, _vp]),
     "bbh_tree_stats": (_int, [_vp, _vp]),
     "bbh_tree_kernel_counts": (_int, [_vp, _vp]),
+    "bbh_tree_memory": (_int, [_vp, _vp]),
+    "bbh_tree_compact": (_int, [_vp, _i32]),
     "bbh_profile_enable": (_int, [_int]),
     "bbh_profile_reset": (_int, []),
     "bbh_profile_get": (_int, [C.c_char_p, C.POINTER(_i64), C.POINTER(_f64)]),

@@ -42,6 +42,8 @@
 
 #include <chrono>
 
+#include <rocprim/device/device_scan.hpp>
+
 #include <algorithm>
 #include <cmath>
 #include <future>
@@ -64,6 +66,23 @@ constexpr int SPLIT_MLP = 16;  // uint8 member CF rows requested before the firs
 constexpr int SPLIT_MLP_WIDE = 4;  // same for rows of mixed width (32 B per thread and row)
 constexpr int NPLT = 11;  // bit planes of a whole-node row count (<= 1024)
 constexpr int MAXM = 4;  // levels of the current root-to-leaf path mirrored in LDS
+// Node storage (round 5): the row pools are cut into BLOCKS of NG rows.  A node id is the index of the node's first block
+// (its rows start at row id * NG of every pool, its header is entry id of the header pool) and a node owns as many blocks
+// as its CAPACITY needs: bf + 1 rows while it is being inserted into, its length rounded up to a block once the compaction
+// (gc_compact, host side) has found it unchanged since the previous compaction ("sealed").  The reference's node is a Python
+// list that grows (bitbirch.py:264-287); a fixed (bf + 1)-row reservation cost 75.5 KB per node at bf 254 whatever it
+// held - 3.2-4.8 GB per million S-ecfp fingerprints, whose leaves stay a tenth full.  Readers may still request bf + 1
+// rows from any node (rows >= len are masked; the pools end in a pad of bf + 1 rows); whoever is about to WRITE to a node
+// meets its header first, and a sealed node is moved to a fresh full-capacity block before anything else happens to it
+// (thaw_node: complete engine; the steady-state and pipelined kernels hand the element over).
+constexpr uint32_t NG = 4;
+__host__ __device__ constexpr uint32_t node_blocks(uint32_t rows) { return (rows + NG - 1) / NG; }
+// header word 1 ("leaf word"): bit 0 leaf flag; bits 4..15 the node's length at the last compaction + 1 (0: it has not seen
+// one); bits 16..31 capacity in rows (0: this block does not start a live node)
+constexpr uint32_t HW_LEAF = 1u;
+__host__ __device__ constexpr uint32_t hw_make(uint32_t leaf, uint32_t cap_rows) { return (leaf & 1u) | (cap_rows << 16); }
+__host__ __device__ constexpr uint32_t hw_cap(uint32_t w) { return w >> 16; }
+__host__ __device__ constexpr uint32_t hw_gcl(uint32_t w) { return (w >> 4) & 0xFFFu; }
 
 enum StopReason : int32_t {
     STOP_DONE = 0,
@@ -73,7 +92,7 @@ enum StopReason : int32_t {
     STOP_CF32 = 5,
     STOP_DEPTH = 6,
     STOP_RANGE = 7,  // n_samples would exceed 2^32-1
-    STOP_GATE = 8,   // a gate node would have to split inside a concurrent batch (admission bug)
+    STOP_GATE = 8,   // a gate node would have to split inside a concurrent batch (admission bug), or a sealed node was met there
 };
 
 enum Ctr : int { C_NODES = 0, C_IDS, C_N8, C_N16, C_N32, C_ROOT, C_FIRST_LEAF, C_DEPTH, C_COUNT };
@@ -270,7 +289,7 @@ struct KCWith : Base {
 struct KC : KCBase {
     static constexpr bool dynamic_shape = true;
     int F, nb, RB, RBc, RBS;
-    uint32_t rows, bf;
+    uint32_t rows, bf, nblk;  // (nblk: blocks of a full-capacity node)
     int nm;  // mirrored levels
     Smem o;
 };
@@ -278,7 +297,7 @@ template <int BF, int NF>
 struct KCFix : KCBase {
     static constexpr bool dynamic_shape = false;
     static constexpr int F = NF, nb = NF / 8, RB = (NF / 8 + 15) / 16 * 16, RBc = RB / 16, RBS = RB + 16;
-    static constexpr uint32_t rows = BF + 1, bf = BF;
+    static constexpr uint32_t rows = BF + 1, bf = BF, nblk = node_blocks(BF + 1);
     static constexpr int nm = mirror_levels(BF, RB);
     static constexpr Smem o = smem_layout(BF, RB, nm);
 };
@@ -585,8 +604,8 @@ __device__ __forceinline__ Cand node_best(const KCt& k, int& cmp_par, uint32_t n
     LA uint32_t* s_i = lds<uint32_t>(k.L, second ? k.o.i2 : k.o.i1);
     LA uint32_t* s_u = lds<uint32_t>(k.L, second ? k.o.u2 : k.o.u1);
     LA u64* wb = lds<u64>(k.L, k.o.wbest) + cmp_par * TW;
-    const size_t meta = (size_t)nd * rows;
-    uint32_t len = 0, leaf = 0;
+    const size_t meta = (size_t)nd * NG;
+    uint32_t len = 0, leaf = 0;  // (leaf: the header's whole leaf word - flag, compaction record, capacity)
     u32x4_t hraw = (u32x4_t)(0);
     const bool load_hdr = !ROOT && known_len < 0;
     if (load_hdr) hraw = ldg<u32x4_t>(k.hdr + nd);  // issued before the rows, same round trip
@@ -903,7 +922,7 @@ __device__ __forceinline__ Cand node_best_mirror(const KCt& k, int& cmp_par, uin
 template <class KCt>
 __device__ __forceinline__ void node_put_row(const KCt& k, uint32_t nd, uint32_t row, uint32_t cent_off, uint32_t card,
                                              uint32_t link, uint32_t sub, uint32_t n, uint32_t slot, u64 s1, u64 s2) {
-    const size_t m = (size_t)nd * k.rows + row;
+    const size_t m = (size_t)nd * NG + row;
     for (int ch = threadIdx.x; ch < k.RBc; ch += TB)
         stg<u32x4_t>(k.cent + m * (size_t)k.RB + (size_t)ch * 16, lds<u32x4_t>(k.L, cent_off)[ch]);
     if (threadIdx.x == 0) {
@@ -1106,8 +1125,8 @@ __device__ __forceinline__ void split_node(const KCt& k, const Elem& el, int& re
     u64 smark = PROF ? __builtin_amdgcn_s_memtime() : 0;
 #define SPH(i) do { if constexpr (PROF) { const u64 _n = __builtin_amdgcn_s_memtime(); sph[i] += _n - smark; smark = _n; } } while (0)
     const uint32_t rows = k.rows;
-    const size_t meta = (size_t)nd * rows;
-    const u32x4_t hold = ldg<u32x4_t>(k.hdr + nd);  // {len, leaf, prev, next}
+    const size_t meta = (size_t)nd * NG;
+    const u32x4_t hold = ldg<u32x4_t>(k.hdr + nd);  // {len, leaf word, prev, next}
     const uint32_t m = uni(hold.x);
     const int nb = k.nb;
     const bool lm = k.nm > 0;  // rows are staged in (or already live in) LDS mirror `ms`
@@ -1234,9 +1253,9 @@ __device__ __forceinline__ void split_node(const KCt& k, const Elem& el, int& re
     }
     // 6. ids for the new node and the two tracking BitFeatures (always cf32): every thread
     //    keeps the (uniform) allocation counters in registers
-    const uint32_t node1 = alloc_n<SUB>(k, cN, gctr + C_NODES, 1, 14);
+    const uint32_t node1 = alloc_n<SUB>(k, cN, gctr + C_NODES, k.nblk, 14);  // (a full-capacity node)
     const uint32_t slotA_i = alloc_n<SUB>(k, c32, gctr + C_N32, 2, 15), slotB_i = slotA_i + 1;
-    const uint32_t was_leaf = uni(hold.y), prev_leaf = uni(hold.z);
+    const uint32_t was_leaf = uni(hold.y) & HW_LEAF, prev_leaf = uni(hold.z);
     if (was_leaf && prev_leaf == NONE) {
         if constexpr (SUB) { if (tid == 0) stg<uint32_t>(gctr + C_FIRST_LEAF, node1); }
         else cFirst = node1;
@@ -1260,9 +1279,10 @@ __device__ __forceinline__ void split_node(const KCt& k, const Elem& el, int& re
         // word-granular header writes: a node's `next` word is only ever written by the split of
         // the node that follows it in the chain, every other word only by its own subtree, so
         // concurrent gates never race on the leaf chain
-        const u32x4_t h = hold;
+        u32x4_t h = hold;
+        h.y &= HW_LEAF;
         u32x4_t h1;
-        h1.x = n1; h1.y = h.y; h1.z = NONE; h1.w = NONE;
+        h1.x = n1; h1.y = hw_make(h.y, rows); h1.z = NONE; h1.w = NONE;
         if (h.y) {
             h1.z = h.z;
             if (h.z != NONE) stg<uint32_t>((uint8_t*)(k.hdr + h.z) + 12, node1);
@@ -1274,7 +1294,7 @@ __device__ __forceinline__ void split_node(const KCt& k, const Elem& el, int& re
     }
     // 7b. distribute rows in their original order
     {
-        uint8_t* cent1 = k.cent + (size_t)node1 * rows * (size_t)k.RB;
+        uint8_t* cent1 = k.cent + (size_t)node1 * NG * (size_t)k.RB;
         for (uint32_t i = tid; i < m * (uint32_t)k.RBc; i += TB) {
             const uint32_t r = i / k.RBc, ch = i % k.RBc;
             const uint32_t d = dst[r];
@@ -1286,7 +1306,7 @@ __device__ __forceinline__ void split_node(const KCt& k, const Elem& el, int& re
         }
         for (uint32_t r = tid; r < m; r += TB) {
             const uint32_t d = dst[r];
-            const size_t mm = ((d & 0x80000000u) ? (size_t)node1 * rows : meta) + (d & 0x7FFFFFFFu);
+            const size_t mm = ((d & 0x80000000u) ? (size_t)node1 * NG : meta) + (d & 0x7FFFFFFFu);
             stg<uint32_t>(k.card + mm, mcard[r]);
             stg<uint32_t>(k.link + mm, mlink[r]);
             stg<u32x4_t>((uint8_t*)(k.rm + mm), mrm[2 * r]);
@@ -1440,7 +1460,7 @@ template <class KCt>
 __device__ __forceinline__ void update_tracker_slow(const KCt& k, const Elem& el, int& red_slot, int lvl, int& stop) {
     const int tid = threadIdx.x;
     const uint32_t P = uni(lds<uint32_t>(k.L, k.o.path_node)[lvl]), jp = uni(lds<uint32_t>(k.L, k.o.path_row)[lvl]);
-    const size_t pm = (size_t)P * k.rows + jp;
+    const size_t pm = (size_t)P * NG + jp;
     const uint32_t slotw = uni(lds<uint32_t>(k.L, k.o.path_slot)[lvl]);
     const u64 n_new = (u64)uni(lds<uint32_t>(k.L, k.o.path_n)[lvl]) + el.nS;
     u64 cc[1] = {0};
@@ -1464,6 +1484,48 @@ __device__ __forceinline__ void update_tracker_slow(const KCt& k, const Elem& el
     }
 }
 
+// A sealed node (capacity below bf + 1: the compaction found it unchanged since the one before) is about to be inserted
+// into: move it to a fresh full-capacity block.  Rows, per-row words and records are copied, the header is written with
+// full capacity (and no compaction record), the leaf chain's neighbours and the parent's row (or the root) are pointed
+// at the new id, the old header is cleared (its blocks are reclaimed by the next compaction).  Whole workgroup; ends with
+// a barrier behind which the new node is complete in HBM for every thread of the workgroup.
+template <class KCt>
+__device__ __forceinline__ uint32_t thaw_node(const KCt& k, uint32_t nd, uint32_t P, uint32_t jp, uint32_t& cN, uint32_t& cRoot,
+                                              uint32_t& cFirst) {
+    const int tid = threadIdx.x;
+    const u32x4_t h = ldg<u32x4_t>(k.hdr + nd);
+    const uint32_t len = uni(h.x), hw = uni(h.y), prev = uni(h.z), next = uni(h.w);
+    const uint32_t nn = cN;
+    cN += k.nblk;
+    const size_t so = (size_t)nd * NG, dn = (size_t)nn * NG;
+    for (uint32_t i = tid; i < len * (uint32_t)k.RBc; i += TB)
+        stg<u32x4_t>(k.cent + dn * (size_t)k.RB + (size_t)i * 16, ldg<u32x4_t>(k.cent + so * (size_t)k.RB + (size_t)i * 16));
+    for (uint32_t r = tid; r < len; r += TB) {
+        stg<uint32_t>(k.card + dn + r, ldg<uint32_t>(k.card + so + r));
+        stg<uint32_t>(k.link + dn + r, ldg<uint32_t>(k.link + so + r));
+        stg<u32x4_t>((uint8_t*)(k.rm + dn + r), ldg<u32x4_t>((const uint8_t*)(k.rm + so + r)));
+        stg<u32x4_t>((uint8_t*)(k.rm + dn + r) + 16, ldg<u32x4_t>((const uint8_t*)(k.rm + so + r) + 16));
+    }
+    if (tid == 0) {
+        u32x4_t hn;
+        hn.x = len; hn.y = hw_make(hw, k.rows); hn.z = prev; hn.w = next;
+        stg<u32x4_t>(k.hdr + nn, hn);
+        if (hw & HW_LEAF) {
+            if (prev != NONE) stg<uint32_t>((uint8_t*)(k.hdr + prev) + 12, nn);
+            if (next != NONE) stg<uint32_t>((uint8_t*)(k.hdr + next) + 8, nn);
+        }
+        if (P != NONE) stg<uint32_t>(k.link + (size_t)P * NG + jp, nn);
+        u32x4_t dead;
+        dead.x = 0; dead.y = 0; dead.z = NONE; dead.w = NONE;
+        stg<u32x4_t>(k.hdr + nd, dead);
+        lds<u64>(k.L, k.o.stats)[7]++;  // (statistics: nodes thawed)
+    }
+    if ((hw & HW_LEAF) && prev == NONE) cFirst = nn;
+    if (P == NONE) cRoot = nn;
+    __syncthreads();
+    return nn;
+}
+
 // one tree per workgroup.  ONE: the cold path of the fast kernel (bb_tree_fast.inc) - insert exactly element
 // `e_first` of tree `trees`; allocation counters and statistics live in LDS (o.ctr / o.stats) across calls, the
 // stop reason and the number of processed elements are returned through o.ctr[8] / o.ctr[9].
@@ -1480,7 +1542,7 @@ __device__ __forceinline__ void tree_insert_body(unsigned char* smem_raw, TreeDe
     k.L = (LA unsigned char*)smem_raw;
     if constexpr (KCt::dynamic_shape) {  // shape of the tree as run-time values
         k.F = (int)uni((uint32_t)T->F); k.nb = (int)uni((uint32_t)T->nbytes); k.RB = (int)uni((uint32_t)T->RB); k.RBc = k.RB / 16; k.RBS = k.RB + 16;
-        k.bf = uni((uint32_t)T->bf); k.rows = k.bf + 1;
+        k.bf = uni((uint32_t)T->bf); k.rows = k.bf + 1; k.nblk = node_blocks(k.rows);
         k.nm = (int)uni((uint32_t)T->use_root_cache);  // number of mirrored path levels
         k.o = smem_layout((int)k.bf, k.RB, k.nm);
     }
@@ -1555,12 +1617,13 @@ __device__ __forceinline__ void tree_insert_body(unsigned char* smem_raw, TreeDe
         if constexpr (!SUB) {
             const uint32_t depth = cDepth;
             if (depth + 2 >= (uint32_t)MAXD) { stop = STOP_DEPTH; break; }
-            if (cN + depth + 2 > cap_nodes) { stop = STOP_NODES; break; }
+            // (every level may split - a node each, and a new root - and every node of the path may have to be thawed first)
+            if (cN + (2 * depth + 2) * k.nblk > cap_nodes) { stop = STOP_NODES; break; }
             if (c8 + 1 > cap8) { stop = STOP_CF8; break; }
             if (c16 + 1 > cap16) { stop = STOP_CF16; break; }
             if (c32 + 2 * (depth + 1) + 1 > cap32) { stop = STOP_CF32; break; }
         }
-        const uint32_t root = cRoot;
+        uint32_t root = cRoot;
         uint32_t root_len;
         if (root_hit) root_len = mir_len[0];
         else root_len = uni(ldg<uint32_t>(k.hdr + root));
@@ -1683,6 +1746,18 @@ __device__ __forceinline__ void tree_insert_body(unsigned char* smem_raw, TreeDe
                     const bool fill = depth < nm;
                     best = node_best<false, false>(k, cmp_par, nd, -1, k.o.x, el.pcx, false, false, true, &len, &leaf,
                                                    (uint32_t)depth, fill, &anyc);
+                    if (hw_cap(leaf) < k.rows) {
+                        // a sealed node: nothing is written to it where it lies (bb_tree.hip, "Node storage")
+                        if constexpr (SUB) { bad = true; break; }  // (concurrent gates: the host thaws the whole tree first)
+                        const uint32_t pP = depth > 0 ? uni(path_node[depth - 1]) : NONE, pj = depth > 0 ? uni(path_row[depth - 1]) : 0u;
+                        __syncthreads();  // (path_node / path_row of the level above were written by thread 0)
+                        nd = thaw_node(k, nd, pP, pj, cN, cRoot, cFirst);
+#pragma unroll
+                        for (int q = 0; q < MAXM; ++q) mir_node[q] = NONE;  // (the parent's mirror holds the old child id)
+                        if (depth == 0) root = nd;
+                        continue;
+                    }
+                    leaf &= HW_LEAF;
                     j = best.r;
                     link = uni(lds<uint32_t>(k.L, k.o.link)[cmp_par * k.rows + j]);
                     if (fill) {
@@ -1716,7 +1791,7 @@ __device__ __forceinline__ void tree_insert_body(unsigned char* smem_raw, TreeDe
                     stats[1] += len;
                 }
                 {
-                    const uint8_t* rmp = (const uint8_t*)(k.rm + (size_t)nd * k.rows + j);
+                    const uint8_t* rmp = (const uint8_t*)(k.rm + (size_t)nd * NG + j);
                     rm0 = ldg<u32x4_t>(rmp);
                     rm1 = ldg<u32x4_t>(rmp + 16);
                 }
@@ -1743,7 +1818,7 @@ __device__ __forceinline__ void tree_insert_body(unsigned char* smem_raw, TreeDe
             const int DT = D < MAXFAST ? D : MAXFAST;  // ancestors handled in the fused pass
             u32x4_t rawL[2] = {(u32x4_t)(0), (u32x4_t)(0)};
             uint32_t vT[MAXFAST][8];
-            const uint8_t* const crowT = k.cent + ((size_t)leafnode * k.rows + jl) * (size_t)k.RB;  // (a lazy BitFeature's cluster features)
+            const uint8_t* const crowT = k.cent + ((size_t)leafnode * NG + jl) * (size_t)k.RB;  // (a lazy BitFeature's cluster features)
             uint32_t cbyteT = 0;
             if (act) {
                 // (whether the BitFeature has one member is not known yet: both its slot - reserved, possibly never
@@ -1814,7 +1889,7 @@ __device__ __forceinline__ void tree_insert_body(unsigned char* smem_raw, TreeDe
             const u64 s1n = s1T + el.s1S;
             const u64 s2n = s2T + 2ull * dot + el.s2S;
             const bool accept = merge_accept(k, el, red_slot, slotE, crowT, nT, s1T, s2T, new_n, s1n, s2n);
-            const size_t leafm = (size_t)leafnode * k.rows;
+            const size_t leafm = (size_t)leafnode * NG;
             if (accept) {
                 // replace_n_samples_and_linear_sum (bitbirch.py:476-484)
                 const uint32_t old_tier = slotT >> 30;
@@ -1918,7 +1993,7 @@ __device__ __forceinline__ void tree_insert_body(unsigned char* smem_raw, TreeDe
                     for (int q = 0; q < MAXFAST; ++q) {
                         if (q < DT) {
                             const uint32_t P = uni(path_node[q]), jp = uni(path_row[q]);
-                            const size_t pm = (size_t)P * k.rows + jp;
+                            const size_t pm = (size_t)P * NG + jp;
                             const u64 n_new = (u64)tn[q] + el.nS;
                             if (n_new > 0xFFFFFFFFull) stop = STOP_RANGE;
                             if (act) {
@@ -1976,14 +2051,15 @@ __device__ __forceinline__ void tree_insert_body(unsigned char* smem_raw, TreeDe
                 }
                 if (lvl == 0) {
                     // root split: new root holding the two tracking BitFeatures
-                    const uint32_t nr = cN++;
+                    const uint32_t nr = cN;
+                    cN += k.nblk;
                     cRoot = nr;
                     cDepth++;
                     node_put_row(k, nr, 0, k.o.cA, cardA, node1, NONE, nA, slotA, 0, 0);
                     node_put_row(k, nr, 1, k.o.cB, cardB, nd, NONE, nB, slotB, 0, 0);
                     if (tid == 0) {
                         u32x4_t h;
-                        h.x = 2; h.y = 0; h.z = NONE; h.w = NONE;
+                        h.x = 2; h.y = hw_make(0u, k.rows); h.z = NONE; h.w = NONE;
                         stg<u32x4_t>(k.hdr + nr, h);
                         stats[5]++;
                     }
@@ -2167,7 +2243,7 @@ __device__ __forceinline__ KC make_kc(TreeDev* T, unsigned char* smem_raw, int n
     k.bufs = nullptr; k.width = 0;
     k.F = (int)uni((uint32_t)T->F); k.nb = (int)uni((uint32_t)T->nbytes); k.RB = (int)uni((uint32_t)T->RB);
     k.RBc = k.RB / 16; k.RBS = k.RB + 16;
-    k.bf = uni((uint32_t)T->bf); k.rows = k.bf + 1;
+    k.bf = uni((uint32_t)T->bf); k.rows = k.bf + 1; k.nblk = node_blocks(k.rows);
     k.crit = 0; k.tol_len = 0; k.thr = 0; k.tolerance = 0; k.tol = nullptr;
     k.nm = nm;
     k.L = (LA unsigned char*)smem_raw;
@@ -2200,7 +2276,7 @@ __global__ __launch_bounds__(TB) void k_route(TreeDev* T, long long first_idx, u
         const Cand best = node_best<false, false>(k, cmp_par, nd, -1, k.o.x, pcx, false, false, true, &len, &leaf);
         const uint32_t link = uni(lds<uint32_t>(k.L, k.o.link)[cmp_par * k.rows + best.r]);
         if (l < G) {
-            const uint32_t fd = uni(ldg<uint32_t>((const uint8_t*)(k.rm + (size_t)nd * k.rows + best.r) + 12));
+            const uint32_t fd = uni(ldg<uint32_t>((const uint8_t*)(k.rm + (size_t)nd * NG + best.r) + 12));
 #pragma unroll
             for (int q = 0; q < 4; ++q)
                 if ((uint32_t)q == l) { rec.node[q] = nd; rec.row[q] = best.r; rec.fd[q] = fd; }
@@ -2228,10 +2304,9 @@ __global__ __launch_bounds__(TB) void k_upd(TreeDev* T, const uint32_t* u_node, 
     __shared__ uint32_t s_fd[TW];
     const int tid = threadIdx.x;
     const uint32_t F = (uint32_t)T->F, nb = (uint32_t)T->nbytes, RB = (uint32_t)T->RB;
-    const size_t rows = (size_t)T->bf + 1;
     const uint32_t nd = u_node[blockIdx.x], r = u_row[blockIdx.x];
     const uint32_t e0 = u_off[blockIdx.x], e1 = u_off[blockIdx.x + 1];
-    const size_t m = (size_t)nd * rows + r;
+    const size_t m = (size_t)nd * NG + r;
     RowMeta* rm = T->node_rm + m;
     const uint32_t slot = rm->slot & 0x3FFFFFFFu;
     const unsigned long long n_new = (unsigned long long)rm->n + (e1 - e0);
@@ -2289,16 +2364,15 @@ __global__ __launch_bounds__(256) void k_gather_leaves(TreeDev* Tp, const uint32
     const TreeDev t = *Tp;
     const long long i = blockIdx.x;
     if (i >= m) return;
-    const size_t rows = (size_t)t.bf + 1;
     const uint32_t nd = nodes[i], r = rowsidx[i];
-    const RowMeta rm = t.node_rm[(size_t)nd * rows + r];
+    const RowMeta rm = t.node_rm[(size_t)nd * NG + r];
     const uint32_t n = rm.n;
     if (threadIdx.x == 0) {
         if (out_n) out_n[i] = n;
         if (out_ids) out_ids[i] = rm.sub;
     }
     if (out_cent) {
-        const uint8_t* src = t.node_cent + ((size_t)nd * rows + r) * (size_t)t.RB;
+        const uint8_t* src = t.node_cent + ((size_t)nd * NG + r) * (size_t)t.RB;
         for (int b = threadIdx.x; b < t.nbytes; b += blockDim.x) out_cent[(size_t)i * t.nbytes + b] = src[b];
     }
     if (out_bufs) {
@@ -2309,7 +2383,7 @@ __global__ __launch_bounds__(256) void k_gather_leaves(TreeDev* Tp, const uint32
         for (int j = threadIdx.x; j < t.F + (ls_only ? 0 : 1); j += blockDim.x) {
             unsigned long long v;
             if (j == t.F) v = n;
-            else if (n == 1) v = (t.node_cent[((size_t)nd * rows + r) * (size_t)t.RB + (size_t)(j >> 3)] >> (7 - (j & 7))) & 1u;
+            else if (n == 1) v = (t.node_cent[((size_t)nd * NG + r) * (size_t)t.RB + (size_t)(j >> 3)] >> (7 - (j & 7))) & 1u;
             else v = tier == 0 ? t.cf8[base + j] : (tier == 1 ? t.cf16[base + j] : t.cf32[base + j]);
             const size_t o = (size_t)i * cols + j;
             switch (width) {
@@ -2318,6 +2392,62 @@ __global__ __launch_bounds__(256) void k_gather_leaves(TreeDev* Tp, const uint32
                 case 4: reinterpret_cast<uint32_t*>(out_bufs)[o] = (uint32_t)v; break;
                 default: reinterpret_cast<unsigned long long*>(out_bufs)[o] = v; break;
             }
+        }
+    }
+}
+
+// ---- compaction of the node pools (gc_nodes, host side; "Node storage" at the top of this file) -------------------
+// Pass 1, one thread per block of the used part of the pool: how many blocks the node that starts here gets in the new
+// pool - 0 for a block that starts no live node; its length rounded up to a block for a node that is sealed already or
+// whose length is what it was at the previous compaction (`seal`; never the root); bf + 1 rows otherwise.
+__global__ __launch_bounds__(256) void k_gc_size(const NodeHdr* __restrict__ hdr, uint32_t used, uint32_t rows, uint32_t root, int seal,
+                                                 uint32_t* __restrict__ sz, unsigned long long* __restrict__ counts) {
+    const uint32_t b = blockIdx.x * 256u + threadIdx.x;
+    if (b >= used) return;
+    const NodeHdr h = hdr[b];
+    const uint32_t cap = hw_cap(h.leaf);
+    uint32_t blocks = 0;
+    if (cap != 0) {
+        const bool cold = seal != 0 && b != root && (cap < rows || hw_gcl(h.leaf) == h.len + 1);
+        const uint32_t len1 = h.len > 0 ? h.len : 1u;
+        blocks = cold ? node_blocks(len1) : node_blocks(rows);
+        atomicAdd(counts + (cold ? 1 : 0), 1ull);  // [0] nodes kept at full capacity, [1] sealed nodes
+    }
+    sz[b] = blocks;
+}
+
+// Pass 2 (after the exclusive prefix sum of the sizes = the new ids), one wave per live node, grid-stride: rows, per-row words
+// and records move to the node's new place in the NEW pools; child ids of internal rows and the leaf chain's ids are
+// translated; the header records the node's length (the next compaction compares with it) and its new capacity.
+__global__ __launch_bounds__(256) void k_gc_move(TreeDev old_t, TreeDev new_t, uint32_t used, uint32_t rows, const uint32_t* __restrict__ sz,
+                                                 const uint32_t* __restrict__ newid) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t waves = gridDim.x * 4u;
+    for (uint32_t b = blockIdx.x * 4u + (threadIdx.x >> 6); b < used; b += waves) {
+        const uint32_t blocks = sz[b];
+        if (blocks == 0) continue;
+        const NodeHdr h = old_t.node_hdr[b];
+        const uint32_t nb_ = newid[b], len = h.len;
+        const bool leaf = (h.leaf & HW_LEAF) != 0;
+        const size_t so = (size_t)b * NG, dn = (size_t)nb_ * NG;
+        const uint32_t rbc = (uint32_t)old_t.RB / 16;
+        const uint4* src = (const uint4*)(old_t.node_cent + so * (size_t)old_t.RB);
+        uint4* dst = (uint4*)(new_t.node_cent + dn * (size_t)old_t.RB);
+        for (uint32_t i = lane; i < len * rbc; i += 64) dst[i] = src[i];
+        for (uint32_t r = lane; r < len; r += 64) {
+            new_t.node_card[dn + r] = old_t.node_card[so + r];
+            const uint32_t lk = old_t.node_link[so + r];
+            new_t.node_link[dn + r] = leaf ? lk : (lk < used ? newid[lk] : lk);
+            new_t.node_rm[dn + r] = old_t.node_rm[so + r];
+        }
+        if (lane == 0) {
+            NodeHdr hn;
+            hn.len = len;
+            const uint32_t cap = blocks == node_blocks(rows) ? rows : blocks * NG;
+            hn.leaf = (h.leaf & HW_LEAF) | (((len + 1) & 0xFFFu) << 4) | (cap << 16);
+            hn.prev = (h.prev != NONE && h.prev < used) ? newid[h.prev] : NONE;
+            hn.next = (h.next != NONE && h.next < used) ? newid[h.next] : NONE;
+            new_t.node_hdr[nb_] = hn;
         }
     }
 }
@@ -2344,6 +2474,10 @@ struct bbh_tree {
     // the launches the pipelined kernel ended with STOP_PIPE_UNSUPPORTED and the pool-exhaustion stops (STOP_NODES / STOP_CF*)
     uint64_t kcount[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     bool pipe_ml = false;  // the pipelined kernel asked for its multi-level instance (informative levels above the leaf-parents)
+    // node-pool compactions (gc_nodes): how many ran, nodes they sealed / left at full capacity (last one), blocks before / after (last one)
+    uint64_t gc_runs = 0, gc_sealed = 0, gc_full = 0, gc_before = 0, gc_after = 0;
+    bool no_seal = false;  // (while the exact batch mode runs: compactions leave every node at full capacity)
+    size_t peak_bytes = 0;  // largest sum of this tree's pool allocations (both copies of a pool that is being regrown included)
 };
 
 namespace {
@@ -2391,28 +2525,182 @@ static uint32_t fit_to_memory(uint32_t want, uint32_t floor_elems, uint32_t cap,
     return (uint32_t)std::min<uint64_t>(most, 0x3FFFFFFFull);
 }
 
-int grow_nodes(bbh_tree* t, uint32_t want) {
+// bytes one block of NG rows takes in the five node pools
+static size_t block_bytes(const TreeDev& h) { return (size_t)NG * ((size_t)h.RB + 40) + sizeof(NodeHdr); }
+static size_t pool_bytes(const TreeDev& h) {
+    const size_t F = (size_t)h.F;
+    return (size_t)h.cap_nodes * block_bytes(h) + (size_t)h.cap8 * F + (size_t)h.cap16 * F * 2 + (size_t)h.cap32 * F * 4;
+}
+static void note_peak(bbh_tree* t, size_t extra) { t->peak_bytes = std::max(t->peak_bytes, pool_bytes(t->h) + extra); }
+
+// The node pools hold `blocks` blocks of NG rows and end in a pad of bf + 1 rows: a node compare requests bf + 1 rows from
+// wherever a node starts, whatever its capacity (rows beyond its length are masked).
+static size_t pool_rows(const TreeDev& h, size_t blocks) { return blocks * NG + (size_t)h.bf + 1 + NG; }
+
+// new node pools of `nc` blocks; the first `keep` blocks of the old ones are carried over (`keep` == 0: nothing).  Headers
+// beyond `keep` are zeroed: a header with capacity 0 starts no node, which is how the compaction tells a node's first
+// block from its other blocks and from blocks that were given up (thaw_node).
+static int realloc_node_pools(bbh_tree* t, size_t keep, size_t nc, TreeDev* fresh_only = nullptr) {
+    TreeDev& h = t->h;
+    const size_t rb = (size_t)h.RB;
+    TreeDev n = h;
+    n.node_cent = nullptr; n.node_card = nullptr; n.node_link = nullptr; n.node_rm = nullptr; n.node_hdr = nullptr;
+    const size_t nr = pool_rows(h, nc);
+    hipError_t e = bb::dev_alloc(&n.node_cent, nr * rb + 64);
+    if (e == hipSuccess) e = bb::dev_alloc(&n.node_card, nr * 4 + 64);
+    if (e == hipSuccess) e = bb::dev_alloc(&n.node_link, nr * 4 + 64);
+    if (e == hipSuccess) e = bb::dev_alloc(&n.node_rm, nr * sizeof(RowMeta) + 64);
+    if (e == hipSuccess) e = bb::dev_alloc(&n.node_hdr, (nc + 1) * sizeof(NodeHdr));
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        void* ptrs[] = {n.node_cent, n.node_card, n.node_link, n.node_rm, n.node_hdr};
+        for (void* q : ptrs)
+            if (q) bb::dev_free(q);
+        return bb::fail(BBH_ERR_CAPACITY, "node pools of %zu blocks (%.2f GB) could not be allocated: %s", nc, (double)nc * (double)block_bytes(h) / 1e9,
+                        hipGetErrorString(e));
+    }
+    note_peak(t, nc * block_bytes(h));
+    if (fresh_only) {  // (the compaction fills the new pools itself and swaps them in)
+        BB_HIP(hipMemset(n.node_hdr, 0, (nc + 1) * sizeof(NodeHdr)));
+        *fresh_only = n;
+        return BBH_OK;
+    }
+    if (keep) {
+        const size_t kr = keep * NG;
+        BB_HIP(hipMemcpy(n.node_cent, h.node_cent, kr * rb, hipMemcpyDeviceToDevice));
+        BB_HIP(hipMemcpy(n.node_card, h.node_card, kr * 4, hipMemcpyDeviceToDevice));
+        BB_HIP(hipMemcpy(n.node_link, h.node_link, kr * 4, hipMemcpyDeviceToDevice));
+        BB_HIP(hipMemcpy(n.node_rm, h.node_rm, kr * sizeof(RowMeta), hipMemcpyDeviceToDevice));
+        BB_HIP(hipMemcpy(n.node_hdr, h.node_hdr, keep * sizeof(NodeHdr), hipMemcpyDeviceToDevice));
+    }
+    BB_HIP(hipMemset(n.node_hdr + keep, 0, (nc + 1 - keep) * sizeof(NodeHdr)));
+    void* old[] = {h.node_cent, h.node_card, h.node_link, h.node_rm, h.node_hdr};
+    for (void* q : old)
+        if (q) bb::dev_free(q);
+    h.node_cent = n.node_cent; h.node_card = n.node_card; h.node_link = n.node_link; h.node_rm = n.node_rm; h.node_hdr = n.node_hdr;
+    h.cap_nodes = (uint32_t)nc;
+    return BBH_OK;
+}
+
+// BBHIP_GC_MIN_MB: node pools below this size grow by plain copying (no compaction, nothing is ever sealed): 1024 by default,
+// 0 in the tests that want every growth to compact.  BBHIP_GC=0 switches the compaction off altogether.
+static size_t gc_min_bytes() {
+    const char* off = getenv("BBHIP_GC");
+    if (off != nullptr && std::strcmp(off, "0") == 0) return (size_t)-1;
+    const char* v = getenv("BBHIP_GC_MIN_MB");  // (read on every call: tests switch it inside one process)
+    return (v != nullptr && v[0] != '\0') ? (size_t)std::strtoull(v, nullptr, 10) << 20 : (size_t)1024 << 20;
+}
+
+// Compaction of the node pools into new ones ("Node storage" at the top of this file): every live node moves to the next free
+// blocks in id order - nodes that are sealed, or (with `seal`) whose length is what the previous compaction recorded, at their
+// length rounded up to a block, the others at full capacity; blocks that thaw_node gave up disappear.  Ids change: child
+// ids, the leaf chain, the root and the first leaf are translated; nothing on the host outlives a call with node ids in it
+// except the leaf chain's copy, which is dropped.  The new pools hold what is live afterwards plus `extra` blocks, or a
+// quarter more if that is more.  seal == 0 brings every node back to full capacity (the exact batch mode wants that).
+int gc_nodes(bbh_tree* t, uint64_t extra, int seal) {
+    TreeDev& h = t->h;
+    const uint32_t used = std::min(h.cap_nodes, h.ctr[C_NODES]);
+    const uint32_t rows = (uint32_t)h.bf + 1;
+    uint32_t *d_sz = nullptr, *d_id = nullptr;
+    unsigned long long* d_cnt = nullptr;
+    void* d_tmp = nullptr;
+    int rc = BBH_OK;
+    TreeDev fresh{};
+    bool have_fresh = false;
+    auto body = [&]() -> int {
+        BB_HIP(bb::dev_alloc(&d_sz, ((size_t)used + 1) * 4));
+        BB_HIP(bb::dev_alloc(&d_id, ((size_t)used + 1) * 4));
+        BB_HIP(bb::dev_alloc(&d_cnt, 16));
+        BB_HIP(hipMemset(d_cnt, 0, 16));
+        BB_HIP(hipMemset(d_sz + used, 0, 4));
+        hipLaunchKernelGGL(k_gc_size, dim3((used + 255) / 256), dim3(256), 0, 0, (const NodeHdr*)h.node_hdr, used, rows, h.ctr[C_ROOT], seal, d_sz, d_cnt);
+        BB_HIP(hipGetLastError());
+        size_t tmp_bytes = 0;
+        BB_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, d_sz, d_id, 0u, (size_t)used + 1, rocprim::plus<uint32_t>(), (hipStream_t)0));
+        BB_HIP(bb::dev_alloc(&d_tmp, tmp_bytes + 16));
+        BB_HIP(rocprim::exclusive_scan(d_tmp, tmp_bytes, d_sz, d_id, 0u, (size_t)used + 1, rocprim::plus<uint32_t>(), (hipStream_t)0));
+        uint32_t total = 0, new_root = 0, new_first = NONE;
+        unsigned long long cnt[2] = {0, 0};
+        BB_HIP(hipMemcpy(&total, d_id + used, 4, hipMemcpyDeviceToHost));
+        BB_HIP(hipMemcpy(&new_root, d_id + h.ctr[C_ROOT], 4, hipMemcpyDeviceToHost));
+        if (h.ctr[C_FIRST_LEAF] != NONE && h.ctr[C_FIRST_LEAF] < used) BB_HIP(hipMemcpy(&new_first, d_id + h.ctr[C_FIRST_LEAF], 4, hipMemcpyDeviceToHost));
+        BB_HIP(hipMemcpy(cnt, d_cnt, 16, hipMemcpyDeviceToHost));
+        // what the new pools hold: everything live, and room for `extra` blocks or a quarter more - within what the device has
+        // free right now (the old pools stay until the move is done)
+        const uint64_t floor_b = (uint64_t)total + (2 * (uint64_t)h.ctr[C_DEPTH] + 8) * node_blocks(rows);
+        uint64_t want = (uint64_t)total + std::max<uint64_t>(extra, tiny_pools() ? 0 : (uint64_t)total / 4);
+        want = std::max(want, floor_b);
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            const uint64_t room = (uint64_t)((double)free_b * 0.92) / block_bytes(h);
+            if (want > room) {
+                // (near the end of the device's memory the pool takes what is left - but not in steps so small that every few
+                // thousand elements copy all of it again: ADVICE r4)
+                const uint64_t least = std::max<uint64_t>(floor_b, (uint64_t)total + std::min<uint64_t>(extra, (uint64_t)total / 32 + 1024));
+                if (room < least)
+                    return bb::fail(BBH_ERR_CAPACITY, "out of device memory: the node pools hold %.2f GB after compaction and %.2f GB are free", (double)total * (double)block_bytes(h) / 1e9, (double)free_b / 1e9);
+                want = room;
+            }
+        } else {
+            (void)hipGetLastError();
+        }
+        if (want > 0x3FFFFFFFull) want = 0x3FFFFFFFull;
+        if (want < floor_b) return bb::fail(BBH_ERR_CAPACITY, "node pool limit of 2^30 blocks reached");
+        BB_TRY(realloc_node_pools(t, 0, (size_t)want, &fresh));
+        have_fresh = true;
+        const uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)used + 3) / 4, 1u << 16);
+        hipLaunchKernelGGL(k_gc_move, dim3(std::max(grid, 1u)), dim3(256), 0, 0, h, fresh, used, rows, (const uint32_t*)d_sz, (const uint32_t*)d_id);
+        BB_HIP(hipGetLastError());
+        BB_HIP(hipDeviceSynchronize());
+        void* old[] = {h.node_cent, h.node_card, h.node_link, h.node_rm, h.node_hdr};
+        for (void* q : old)
+            if (q) bb::dev_free(q);
+        h.node_cent = fresh.node_cent; h.node_card = fresh.node_card; h.node_link = fresh.node_link; h.node_rm = fresh.node_rm; h.node_hdr = fresh.node_hdr;
+        have_fresh = false;
+        h.cap_nodes = (uint32_t)want;
+        t->gc_runs += 1; t->gc_full = cnt[0]; t->gc_sealed = cnt[1]; t->gc_before = used; t->gc_after = total;
+        h.ctr[C_NODES] = total;
+        h.ctr[C_ROOT] = new_root;
+        h.ctr[C_FIRST_LEAF] = new_first;
+        t->chain_valid = false;
+        static const bool gc_log = getenv("BBHIP_GC_LOG") != nullptr;
+        if (gc_log)
+            fprintf(stderr, "[bbhip gc] #%llu blocks %u -> %u (%.3f -> %.3f GB), nodes full %llu sealed %llu, new pool %.3f GB\n", (unsigned long long)t->gc_runs, used, total,
+                    (double)used * (double)block_bytes(h) / 1e9, (double)total * (double)block_bytes(h) / 1e9, cnt[0], cnt[1], (double)want * (double)block_bytes(h) / 1e9);
+        return BBH_OK;
+    };
+    rc = body();
+    if (have_fresh) {
+        void* ptrs[] = {fresh.node_cent, fresh.node_card, fresh.node_link, fresh.node_rm, fresh.node_hdr};
+        for (void* q : ptrs)
+            if (q) bb::dev_free(q);
+    }
+    if (d_sz) bb::dev_free(d_sz);
+    if (d_id) bb::dev_free(d_id);
+    if (d_cnt) bb::dev_free(d_cnt);
+    if (d_tmp) bb::dev_free(d_tmp);
+    return rc;
+}
+
+// `want`: blocks the node pools should hold.  Small pools grow by copying; pools beyond BBHIP_GC_MIN_MB are compacted on the
+// way (gc_nodes), which is where nodes that stopped changing give their unused rows back.
+int grow_nodes(bbh_tree* t, uint32_t want, uint64_t gc_extra = 0) {  // (gc_extra: room a compaction leaves; 0: want - used)
     TreeDev& h = t->h;
     if (want <= h.cap_nodes) return BBH_OK;
-    {
-        const uint32_t floor_elems = clamp30((uint64_t)h.ctr[C_NODES] + 2 * (uint64_t)h.ctr[C_DEPTH] + 64);
-        want = fit_to_memory(grow_target(h.cap_nodes, want), std::max(floor_elems, h.cap_nodes + 1), h.cap_nodes,
-                             ((size_t)h.bf + 1) * ((size_t)h.RB + 40) + 16);
-    }
-    const size_t rows = (size_t)h.bf + 1;
+    const uint32_t nblk = node_blocks((uint32_t)h.bf + 1);
     // a tree that has not received anything yet owns one empty root: nothing to carry over but its
     // 16-byte header (a multiround round creates hundreds of trees and grows each of them once)
-    const bool pristine = h.cap_nodes > 0 && h.ctr[C_NODES] == 1 && h.ctr[C_IDS] == 0 && h.stats[3] == 0;
-    const size_t oc = pristine ? 0 : std::min<size_t>(h.cap_nodes, h.ctr[C_NODES]), nc = want;  // live nodes only
-    BB_TRY(grow_pool(h.node_cent, oc * rows * h.RB, nc * rows * h.RB));
-    BB_TRY(grow_pool(h.node_card, oc * rows, nc * rows));
-    BB_TRY(grow_pool(h.node_link, oc * rows, nc * rows));
-    BB_TRY(grow_pool(h.node_rm, oc * rows, nc * rows));
-    BB_TRY(grow_pool(h.node_hdr, oc, nc));
-    h.cap_nodes = (uint32_t)nc;
+    const bool pristine = h.cap_nodes > 0 && h.ctr[C_NODES] == nblk && h.ctr[C_IDS] == 0 && h.stats[3] == 0;
+    const uint32_t used = std::min(h.cap_nodes, h.ctr[C_NODES]);
+    if (!pristine && h.cap_nodes > 0 && (size_t)used * block_bytes(h) >= gc_min_bytes()) return gc_nodes(t, gc_extra ? gc_extra : (uint64_t)want - used, t->no_seal ? 0 : 1);
+    {
+        const uint32_t floor_elems = clamp30((uint64_t)h.ctr[C_NODES] + (2 * (uint64_t)h.ctr[C_DEPTH] + 64) * nblk);
+        want = fit_to_memory(grow_target(h.cap_nodes, want), std::max(floor_elems, h.cap_nodes + 1), h.cap_nodes, block_bytes(h));
+    }
+    BB_TRY(realloc_node_pools(t, pristine ? 0 : used, want));
     if (pristine) {
         NodeHdr root;
-        root.len = 0; root.leaf = 1; root.prev = NONE; root.next = NONE;
+        root.len = 0; root.leaf = hw_make(1u, (uint32_t)h.bf + 1); root.prev = NONE; root.next = NONE;
         BB_HIP(hipMemcpy(h.node_hdr, &root, sizeof(root), hipMemcpyHostToDevice));
     }
     return BBH_OK;
@@ -2451,14 +2739,16 @@ void free_pools(bbh_tree* t) {
 int init_empty(bbh_tree* t) {
     TreeDev& h = t->h;
     std::memset(h.ctr, 0, sizeof(h.ctr));
-    BB_TRY(grow_nodes(t, std::max<uint32_t>(h.cap_nodes, 64)));
+    const uint32_t nblk = node_blocks((uint32_t)h.bf + 1);
+    BB_TRY(grow_nodes(t, std::max<uint32_t>(h.cap_nodes, 64 * nblk)));
     BB_TRY(grow_cf(t, 0, std::max<uint32_t>(h.cap8, 1024)));
     BB_TRY(grow_cf(t, 1, std::max<uint32_t>(h.cap16, 64)));
     BB_TRY(grow_cf(t, 2, std::max<uint32_t>(h.cap32, 256)));
     NodeHdr root;
-    root.len = 0; root.leaf = 1; root.prev = NONE; root.next = NONE;
+    root.len = 0; root.leaf = hw_make(1u, (uint32_t)h.bf + 1); root.prev = NONE; root.next = NONE;
+    BB_HIP(hipMemset(h.node_hdr, 0, ((size_t)h.cap_nodes + 1) * sizeof(NodeHdr)));  // (a reset tree: no header of the old one survives)
     BB_HIP(hipMemcpy(h.node_hdr, &root, sizeof(root), hipMemcpyHostToDevice));
-    h.ctr[C_NODES] = 1;
+    h.ctr[C_NODES] = nblk;
     h.ctr[C_N8] = 1;  // (slot 0 of the uint8 pool is SLOT_LAZY8: never a BitFeature's)
     h.ctr[C_ROOT] = 0;
     h.ctr[C_FIRST_LEAF] = 0;
@@ -2572,14 +2862,14 @@ int pregrow(bbh_tree* t, int64_t n, int width) {
     if (tiny_pools()) {
         BB_TRY(grow_cf(t, 0, clamp30((uint64_t)h.ctr[C_N8] + 8)));
         BB_TRY(grow_cf(t, 1, clamp30((uint64_t)h.ctr[C_N16] + 8)));
-        BB_TRY(grow_nodes(t, clamp30((uint64_t)h.ctr[C_NODES] + 8 + h.ctr[C_DEPTH])));
+        BB_TRY(grow_nodes(t, clamp30((uint64_t)h.ctr[C_NODES] + (8 + 2 * (uint64_t)h.ctr[C_DEPTH]) * node_blocks((uint32_t)h.bf + 1))));
         BB_TRY(grow_cf(t, 2, clamp30((uint64_t)h.ctr[C_N32] + 16 + 2 * (uint64_t)h.ctr[C_DEPTH])));
         return BBH_OK;
     }
     const uint64_t un = (uint64_t)std::max<int64_t>(n, 0);
     if (width <= 1) BB_TRY(grow_cf(t, 0, clamp30((uint64_t)h.ctr[C_N8] + un / 8 + 1024)));
     if (width == 2) BB_TRY(grow_cf(t, 1, clamp30((uint64_t)h.ctr[C_N16] + un + 64)));
-    BB_TRY(grow_nodes(t, clamp30((uint64_t)h.ctr[C_NODES] + un / (uint64_t)std::max(1, h.bf / 2) + 64)));
+    BB_TRY(grow_nodes(t, clamp30((uint64_t)h.ctr[C_NODES] + (un / (uint64_t)std::max(1, h.bf / 2) + 64) * node_blocks((uint32_t)h.bf + 1))));
     BB_TRY(grow_cf(t, 2, clamp30((uint64_t)h.ctr[C_N32] + un / (uint64_t)std::max(1, h.bf / 6) + 256)));
     return BBH_OK;
 }
@@ -2855,14 +3145,23 @@ int run_insert_multi(std::vector<Job>& jobs, hipStream_t s) {
             const int64_t left = j.n - j.done;
             // what a pool that ran out is grown to: half as much again, or what the elements that are left are expected to
             // need (pregrow's rates) if that is more
+            uint64_t uleft_for_nodes = 0;
             auto more = [&](uint32_t used, uint32_t cap, uint64_t expect) -> uint32_t {
                 if (tiny_pools()) return clamp30((uint64_t)cap + 8 + 2 * (uint64_t)h.ctr[C_DEPTH]);  // (one insertion's worst case fits)
                 return clamp30(std::max<uint64_t>((uint64_t)cap + cap / 2, (uint64_t)used + expect));
             };
+            const uint64_t nblk = node_blocks((uint32_t)h.bf + 1);
+            // (nodes: blocks; a pool that is compacted on the way - grow_nodes - takes `want - used` as the room asked for)
+            auto more_nodes = [&]() -> uint32_t {
+                if (tiny_pools()) return clamp30((uint64_t)h.ctr[C_NODES] + (8 + 2 * (uint64_t)h.ctr[C_DEPTH]) * nblk);
+                const uint64_t expect = (uleft_for_nodes / (uint64_t)std::max(1, h.bf / 2) + 64) * nblk;
+                return clamp30(std::max<uint64_t>((uint64_t)h.cap_nodes + h.cap_nodes / 2, (uint64_t)h.ctr[C_NODES] + expect));
+            };
             const uint64_t uleft = (uint64_t)std::max<int64_t>(left, 0);
+            uleft_for_nodes = uleft;
             switch (back.stop_reason) {
                 case STOP_DONE: break;
-                case STOP_NODES: rc = grow_nodes(t, more(h.ctr[C_NODES], h.cap_nodes, uleft / (uint64_t)std::max(1, h.bf / 2) + 64)); break;
+                case STOP_NODES: rc = grow_nodes(t, more_nodes(), tiny_pools() ? (8 + 2 * (uint64_t)h.ctr[C_DEPTH]) * nblk : (uleft / (uint64_t)std::max(1, h.bf / 2) + 64) * nblk); break;
                 case STOP_CF8: rc = grow_cf(t, 0, more(h.ctr[C_N8], h.cap8, uleft / 8 + 1024)); break;
                 case STOP_CF16: rc = grow_cf(t, 1, more(h.ctr[C_N16], h.cap16, (j.width == 2 ? uleft : uleft / 64) + 64)); break;
                 case STOP_CF32: rc = grow_cf(t, 2, more(h.ctr[C_N32], h.cap32, uleft / (uint64_t)std::max(1, h.bf / 6) + 256)); break;
@@ -2917,7 +3216,7 @@ int build_chain(bbh_tree* t) {
     t->chain_rows.clear();
     uint32_t nd = h.ctr[C_FIRST_LEAF];
     size_t guard = 0;
-    while (nd != NONE && nd < nn && guard++ <= nn) {
+    while (nd != NONE && nd < nn && guard++ <= nn) {  // (nn: blocks - more than there are nodes)
         for (uint32_t r = 0; r < hdr[nd].len; ++r) {
             t->chain_nodes.push_back(nd);
             t->chain_rows.push_back(r);
@@ -2997,7 +3296,7 @@ extern "C" int bbh_tree_set_merge(bbh_tree* t, int32_t criterion, double toleran
     t->h.thr = threshold;
     BB_TRY(set_tol(t, tol_table, tol_len));
     if (branching_factor != t->h.bf) {
-        const bool empty = t->h.ctr[C_NODES] == 1 && t->h.ctr[C_IDS] == 0;
+        const bool empty = t->h.ctr[C_NODES] == node_blocks((uint32_t)t->h.bf + 1) && t->h.ctr[C_IDS] == 0;
         if (!empty)
             return bb::fail(BBH_ERR_STATE, "branching_factor can only change on an empty tree: call reset() first");
         if (branching_factor < 2 || branching_factor > MAX_BF)
@@ -3378,6 +3677,28 @@ extern "C" int bbh_tree_kernel_counts(bbh_tree* t, uint64_t* out8) {
     if (!t || !out8) return bb::fail(BBH_ERR_INVALID, "null argument");
     for (int i = 0; i < 8; ++i) out8[i] = t->kcount[i];
     return BBH_OK;
+}
+
+extern "C" int bbh_tree_memory(bbh_tree* t, uint64_t* out8) {
+    if (!t || !out8) return bb::fail(BBH_ERR_INVALID, "null argument");
+    const TreeDev& h = t->h;
+    const size_t F = (size_t)h.F;
+    out8[0] = (uint64_t)h.cap_nodes * block_bytes(h);
+    out8[1] = (uint64_t)std::min(h.cap_nodes, h.ctr[C_NODES]) * block_bytes(h);
+    out8[2] = (uint64_t)h.cap8 * F + (uint64_t)h.cap16 * F * 2 + (uint64_t)h.cap32 * F * 4;
+    out8[3] = std::max(t->peak_bytes, pool_bytes(h));
+    out8[4] = t->gc_runs;
+    out8[5] = t->gc_sealed;
+    out8[6] = t->gc_full;
+    out8[7] = h.stats[7];
+    return BBH_OK;
+}
+
+extern "C" int bbh_tree_compact(bbh_tree* t, int32_t seal) {
+    if (!t) return bb::fail(BBH_ERR_INVALID, "null tree");
+    BB_HIP(hipSetDevice(t->device));
+    BB_HIP(hipDeviceSynchronize());
+    return gc_nodes(t, 0, seal != 0 ? 1 : 0);
 }
 
 extern "C" int bbh_tree_stats(bbh_tree* t, uint64_t* out8) {

@@ -35,6 +35,7 @@ REPO = Path(__file__).resolve().parent
 sys.path.insert(0, str(REPO))
 sys.path.insert(0, str(REPO / "tests"))
 
+PREVIOUS_ROUND = "r04"  # profiles/<round>/bench_line_final.json: what `regressions` compares this line with
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 BYTES_PER_FP = 264  # 256 B row read once + 8 B label
 _W8 = [128, 64, 32, 16, 8, 4, 2, 1]
@@ -128,12 +129,46 @@ def synth_hier(n: int, seed: int, device, n_features: int = 2048):
     return out
 
 
+def synth_zipf(n: int, seed: int, device, n_features: int = 2048):
+    r"""Rows with a realistic per-bit frequency profile: bit j of a random permutation of the positions is
+    set with probability p_j = min(0.95, 4 / (j + 1)^0.85) - a Zipf-like tail, 11 bits above 50 % (the substructure bits most
+    molecules share), ~60 bits per row - in n/50 planted prototypes; a row is its prototype with 10 % of its bits dropped and
+    3 % as many drawn afresh from the same profile.  Unlike S-ecfp the common bits keep the tracking centroids of the tree's
+    internal levels non-zero (a majority vote keeps what more than half of the members share), and rows of one prototype
+    merge at threshold 0.3."""
+    import torch
+
+    g = torch.Generator(device=device).manual_seed(seed)
+    rank = torch.randperm(n_features, device=device, generator=g).double()
+    p = torch.clamp(4.0 / (rank + 1.0) ** 0.85, max=0.95).float()
+    k = max(n // 50, 1)
+    weights = torch.tensor(_W8, dtype=torch.int32, device=device)
+    shifts = torch.arange(7, -1, -1, device=device, dtype=torch.uint8)
+    protos = torch.empty((k, n_features // 8), dtype=torch.uint8, device=device)
+    chunk = 50_000
+    for lo in range(0, k, chunk):
+        m = min(chunk, k - lo)
+        bits = (torch.rand((m, n_features), device=device, generator=g) < p).to(torch.int32)
+        protos[lo:lo + m] = (bits.view(m, -1, 8) * weights).sum(dim=2).to(torch.uint8)
+    out = torch.empty((n, n_features // 8), dtype=torch.uint8, device=device)
+    for lo in range(0, n, chunk):
+        m = min(chunk, n - lo)
+        which = torch.randint(0, k, (m,), device=device, generator=g)
+        pb = ((protos[which][:, :, None] >> shifts) & 1).bool().view(m, n_features)
+        keep = torch.rand((m, n_features), device=device, generator=g) > 0.10
+        add = torch.rand((m, n_features), device=device, generator=g) < 0.03 * p
+        bits = ((pb & keep) | add).to(torch.int32)
+        out[lo:lo + m] = (bits.view(m, -1, 8) * weights).sum(dim=2).to(torch.uint8)
+    return out
+
+
 WORKLOADS = {
     # name: (generator, threshold, description)
     "fake": (synth_fake_fps, 0.3, "make_fake_fingerprints popcount distribution"),
     "ecfp": (synth_ecfp, 0.3, "S-ecfp sparse ECFP4-like rows around n/50 planted prototypes"),
     "rdkit": (synth_rdkit_like, 0.6, "S-rdkit-like dense rows (popcount ~N(900,250)) around n/50 planted prototypes"),
     "hier": (synth_hier, 0.6, "two-level planted families (clustered_hier): informative internal tree levels"),
+    "zipf": (synth_zipf, 0.3, "Zipf-like per-bit frequencies (11 bits above 50 %), n/50 planted prototypes that merge at 0.3"),
 }
 
 
@@ -265,6 +300,32 @@ def cpu_multiround_baseline(files: list[Path], bf: int, thr: float, bin_size: in
             "sample": f"{rows} rows of the same workload in {len(files)} shard files; round 1 in {nproc} processes, the "
                       f"merge round's {len(batches)} batches in {nproc2} processes (the reference's pools, multiround.py:419-455), "
                       "the final merge in one"}
+
+
+def regressions(out: dict, prev_file: Path, tolerance: float = 0.05) -> dict:
+    r"""Every throughput of this line next to the same entry of the previous round's committed line: entries more than
+    `tolerance` worse are listed (two regressions went unnoticed for a round).  GPU rates only - the CPU
+    baselines move with the box."""
+    names = {"fingerprints_per_s", "gpu_fingerprints_per_s", "achieved", "value"}
+    try:
+        prev = json.loads(prev_file.read_text())
+    except Exception as exc:
+        return {"against": str(prev_file), "error": repr(exc)[:120]}
+
+    def walk(a, b, path, acc):
+        if isinstance(a, dict) and isinstance(b, dict):
+            for k in a:
+                if k in b and "cpu" not in k and k not in ("projected_8gpu", "traffic_source"):
+                    walk(a[k], b[k], path + [k], acc)
+        elif path and path[-1] in names and isinstance(a, (int, float)) and isinstance(b, (int, float)) and b > 0:
+            acc.append((".".join(path), float(a), float(b)))
+
+    pairs: list = []
+    walk(out, prev, [], pairs)
+    worse = {k: {"now": a, "before": b, "ratio": round(a / b, 3)} for k, a, b in pairs if a < (1.0 - tolerance) * b}
+    better = {k: round(a / b, 3) for k, a, b in pairs if a > (1.0 + tolerance) * b}
+    return {"against": str(prev_file.relative_to(REPO)) if prev_file.is_relative_to(REPO) else str(prev_file), "compared": len(pairs),
+            "tolerance": tolerance, "worse": worse, "better": better}
 
 
 def _free_port() -> int:
@@ -550,21 +611,31 @@ def single_gpu(args: argparse.Namespace) -> None:
     others = None
     if not args.no_extras:
         others = {}
-        for wname in ("ecfp", "rdkit", "hier"):
+        for wname in ("ecfp", "rdkit", "hier", "zipf"):
             if wname == args.workload:
                 continue
             wgen, wthr, _ = WORKLOADS[wname]
             wf = wgen(n, 1000, dev)
             torch.cuda.synchronize()
-            for wbf in ((args.bf,) if wname != "hier" else (args.bf, 254)):
+            for wbf in ((args.bf,) if wname in ("ecfp", "rdkit") else (args.bf, 254)):
                 t1 = time.perf_counter()
                 wt = BitBirch(branching_factor=wbf, threshold=wthr, merge_criterion="diameter", device=local_rank).fit(wf)
                 torch.cuda.synchronize()
                 dt = time.perf_counter() - t1
                 wk = wt._engine.kernel_counts()
-                others[f"{wname}_bf{wbf}"] = {"rows": n, "threshold": wthr, "branching_factor": wbf, "seconds": dt, "fingerprints_per_s": n / dt,
-                                              "elements_by_kernel": {"pipe": int(wk[0]), "fast": int(wk[1]), "complete": int(wk[2])},
-                                              "unsupported_shape_stops": int(wk[6]), "stats": [int(v) for v in wt._engine.stats()[:7]]}
+                wst = [int(v) for v in wt._engine.stats()[:7]]
+                rec = {"rows": n, "threshold": wthr, "branching_factor": wbf, "seconds": dt, "fingerprints_per_s": n / dt,
+                       "elements_by_kernel": {"pipe": int(wk[0]), "fast": int(wk[1]), "complete": int(wk[2])},
+                       "unsupported_shape_stops": int(wk[6]), "stats": wst,
+                       # (of the insertions: how many merged into an existing BitFeature; how many ended as clusters of one)
+                       "merge_fraction": wst[2] / max(wst[2] + wst[3], 1)}
+                if not args.no_cpu:
+                    # the same workload through the C oracle on one host core (a bounded sample: the first 200 k rows)
+                    msamp = min(n, 200_000)
+                    cb = cpu_baseline(wf[:msamp].cpu().numpy(), wbf, wthr)
+                    rec["cpu_baseline"] = {"value": cb["value"], "unit": cb["unit"], "cores": 1, "kind": "port", "rows": msamp}
+                    rec["gpu_over_cpu_core"] = rec["fingerprints_per_s"] / cb["value"]
+                others[f"{wname}_bf{wbf}"] = rec
                 del wt
             del wf
         # the headline workload drawn with other seeds: informative levels above the leaf-parents come and go,
@@ -588,7 +659,11 @@ def single_gpu(args: argparse.Namespace) -> None:
     config3 = None
     if not args.no_extras and args.config3_rows > 0:
         try:
+            sys.path.insert(0, str(REPO / "tools"))
+            from props import check_clustering, column_sums
+
             c3 = synth_ecfp(args.config3_rows, 7, dev)
+            c3_want = column_sums(c3)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             ct = BitBirch(branching_factor=254, threshold=0.3, merge_criterion="diameter", device=local_rank).fit(c3)
@@ -601,6 +676,16 @@ def single_gpu(args: argparse.Namespace) -> None:
             t4 = time.perf_counter()
             config3 = {"rows": args.config3_rows, "branching_factor": 254, "fit_s": t2 - t1, "refine_s": t3 - t2, "labels_s": t4 - t3,
                        "fingerprints_per_s": args.config3_rows / (t4 - t1), "leaf_bitfeatures_after_fit": k_fit, "clusters": int(clab.max())}
+            # (outside the clock) the size-independent properties at this size: the clusters partition 0..n-1, sizes / labels
+            # agree, the final cluster features' column sums are those of all fingerprints (tools/props.py)
+            try:
+                cs = check_clustering(ct, args.config3_rows, c3_want, clab)
+                config3["checked"] = {"partition": True, "column_sums": True, **cs}
+            except AssertionError as exc:
+                config3["checked"] = {"failed": repr(exc)[:200]}
+            mem3 = ct._engine.memory()
+            config3["memory"] = {"node_pools_gb": int(mem3[0]) / 1e9, "node_pools_used_gb": int(mem3[1]) / 1e9, "cf_pools_gb": int(mem3[2]) / 1e9,
+                                 "compactions": int(mem3[4]), "sealed_nodes": int(mem3[5]), "thawed": int(mem3[7])}
             del ct, clab, c3
         except Exception as exc:  # the sub-record must not take the headline down with it
             config3 = {"error": repr(exc)[:200]}
@@ -800,8 +885,11 @@ def single_gpu(args: argparse.Namespace) -> None:
             traffic_source = {"file": "profiles/pmc_latest.json", "kernel_src_sha": rec.get("kernel_src_sha"),
                               "this_build_src_sha": src_sha, "n_fps": rec.get("n_fps")}
             if int(rec.get("n_fps", -1)) == n and rec.get("kernel_src_sha") == src_sha:
-                # FETCH_SIZE/WRITE_SIZE are in KB; FETCH_SIZE reads 1/2 on gfx950 (MI355X_MICROARCH.md)
-                traffic = (2.0 * rec["tree_fetch_kb_total"] + rec["tree_write_kb_total"]) * 1024.0 / max(rec["tree_launches"], 1)
+                # FETCH_SIZE/WRITE_SIZE are in KB; FETCH_SIZE reads 1/2 on gfx950 (MI355X_MICROARCH.md).  Per FIT: the profiled
+                # command runs `fits` fits (tools/profile_bench.sh: one timed step + the end-to-end step), each of them one long
+                # launch of the pipelined kernel (the dominant launch `achieved` is about) next to a 5 us probe and the first
+                # 8 192 elements on k_tree_fast - dividing by all tree-kernel launches read as a third of the truth
+                traffic = (2.0 * rec["tree_fetch_kb_total"] + rec["tree_write_kb_total"]) * 1024.0 / max(int(rec.get("fits", 2)), 1)
         except Exception:
             traffic = None
     out = {
@@ -832,6 +920,8 @@ def single_gpu(args: argparse.Namespace) -> None:
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic,
+            "traffic_per_element": None if traffic is None else traffic / n,
+            "traffic_note": "HBM bytes (FETCH_SIZE x 2 + WRITE_SIZE, separate PMC passes) per FIT = per dominant launch; 264 B x elements algorithmic",
             "traffic_source": traffic_source,
             "launches": k_launches,
             "avg_launch_ms": avg_ms,
@@ -883,6 +973,8 @@ def single_gpu(args: argparse.Namespace) -> None:
         out["cpu_baseline"] = cpu_baseline(fps[:sample].cpu().numpy(), args.bf, args.threshold)
     else:
         out["cpu_baseline"] = None
+    if args.workload == "fake" and n == 1_000_000 and args.bf == 50:
+        out["regressions"] = regressions(out, REPO / "profiles" / PREVIOUS_ROUND / "bench_line_final.json")
     _emit(out)
 
 

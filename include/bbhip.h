@@ -204,6 +204,19 @@ int bbh_tree_stats(bbh_tree* t, uint64_t* out8);
  * ended because a pool was exhausted (the host grew it and relaunched). */
 int bbh_tree_kernel_counts(bbh_tree* t, uint64_t* out8);
 
+/* What the tree holds in HBM and what its node storage did (tests, tools/config45.py, bench.py):
+ * [0] bytes of the node pools (capacity), [1] bytes of their used part, [2] bytes of the uint8 / uint16 / uint32
+ * cluster-feature pools (capacity), [3] largest sum of this tree's allocations so far (a pool that is being regrown
+ * counts twice), [4] compactions of the node pools, [5] nodes the last one sealed (length rounded up to a block of rows
+ * instead of bf + 1 rows: the reference's node is a list that grows, bitbirch.py:264-287), [6] nodes it left at full
+ * capacity, [7] sealed nodes moved back to full capacity because an insertion reached them. */
+int bbh_tree_memory(bbh_tree* t, uint64_t* out8);
+
+/* Compact the node pools now (the engine does it on its own when pools beyond BBHIP_GC_MIN_MB, default 1024, have to
+ * grow): seal != 0 seals every node whose length is what the previous compaction recorded, seal == 0 brings every node
+ * back to full capacity.  Results of later calls do not depend on when or whether this ran. */
+int bbh_tree_compact(bbh_tree* t, int32_t seal);
+
 /* Per-kernel timing with HIP events on the stream each kernel is launched on.
  * bbh_profile_enable(1) turns it on; bbh_profile_get returns launches and summed
  * milliseconds for the kernel called `name` ("jt_arr_vec", "tree_insert", ...; the tree kernels are recorded as

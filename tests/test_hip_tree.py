@@ -290,13 +290,16 @@ def test_hip_batch_mode_concurrent_gates_vs_oracle(n, k, thr, bf, batch, monkeyp
     assert hip._engine.stats()[:7].tolist() == ora._engine.stats()[:7].tolist()
 
 
-def test_hip_batch_mode_fake_vs_serial(monkeypatch):
+def test_hip_batch_mode_fake_vs_oracle(monkeypatch):
+    r"""Batch mode on S-fake rows (every element lands in the same gate: windows of 1-3 elements) against the ORACLE, per element."""
     fps = np.concatenate([make_fake_fingerprints(10_000, seed=300 + i) for i in range(6)])
-    ser = BitBirch(branching_factor=50, threshold=0.3).fit(fps)
+    ora = BitBirch(branching_factor=50, threshold=0.3, _engine_factory=OracleEngine).fit(fps)
     monkeypatch.setenv("BBHIP_BATCH", "256")
     bat = BitBirch(branching_factor=50, threshold=0.3).fit(fps)
     monkeypatch.delenv("BBHIP_BATCH")
-    _same(bat, ser)
+    assert (bat._log_leaf[-1] == ora._log_leaf[-1]).all()
+    _same(bat, ora)
+    assert bat._engine.stats()[:7].tolist() == ora._engine.stats()[:7].tolist()
 
 
 @pytest.mark.gpu

@@ -107,6 +107,23 @@ def test_configs_4_5_distributed_gloo_world2_oracle(case, tmp_path):
     assert ex[1]["round-3"]["received"] == 0  # the final merge happens on rank 0 only
 
 
+@pytest.mark.parametrize("world,case_i,budget", [(4, 0, None), (8, 1, None), (4, 1, 3), (8, 0, 3)],
+                         ids=["cfg4_world4", "cfg5_world8", "cfg5_world4_bounded", "cfg4_world8_bounded"])
+def test_configs_4_5_distributed_gloo_world4_world8_oracle(world, case_i, budget, tmp_path):
+    r"""The plan changes shape with the world size - batch b is merged by rank b mod W, with 8 shard files at W = 8 every rank
+    owns exactly one shard and the merge round's batches land on ranks 0 and 1, the slab schedule of the bounded receive has
+    W - 1 senders per step: 4 and 8 gloo ranks (oracle engine) must reproduce the reference's digests of configs 4 / 5 with
+    and without a receive budget, and account for every byte on the wire."""
+    case = MULTIROUND_SCALE_CASES[case_i]
+    ex = _run_distributed(case, tmp_path, use_oracle=True, backend="gloo", world=world, recv_budget_mb=budget)
+    sent = sum(b["sent"] for per in ex for b in per.values())
+    assert sent == sum(b["received"] for per in ex for b in per.values()) > 0
+    for r in range(1, world):
+        assert ex[r]["round-3"]["received"] == 0  # the final merge happens on rank 0 only
+    # (round 2: the merge round's batches go to ranks b mod W - with 8 tables per dtype and bins of 10 that is ranks 0 and 1)
+    assert all(ex[r]["round-2"]["received"] == 0 for r in range(2, world))
+
+
 from conftest import rccl_world
 
 _RCCL_W = rccl_world()

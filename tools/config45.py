@@ -18,7 +18,7 @@ import sys
 import threading
 import time
 
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
+sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests"); sys.path.insert(0, "/root/repo/tools")
 import numpy as np
 import torch
 
@@ -66,14 +66,13 @@ def main() -> None:
     gen = WORKLOADS[workload][0]
     n = a.shards * a.rows_per_shard
     t0 = time.perf_counter()
+    from props import column_sums
+
     want = torch.zeros(2048, dtype=torch.int64, device=dev)
-    shifts = torch.arange(7, -1, -1, device=dev, dtype=torch.uint8)
     shards = []
     for i in range(a.shards):
         s = gen(a.rows_per_shard, 4000 * a.config + i, dev)
-        for lo in range(0, a.rows_per_shard, 250_000):
-            bits = (s[lo:lo + 250_000, :, None] >> shifts) & 1
-            want += bits.view(-1, 2048).sum(dim=0, dtype=torch.int64)
+        column_sums(s, want)
         shards.append(s.cpu().numpy())
         del s
     torch.cuda.empty_cache()
@@ -103,46 +102,15 @@ def main() -> None:
     print(f"whole job {wall:.1f} s = {n / wall:.0f} fingerprints/s (+ labels {t_assign:.1f} s); peak HBM in use {mon.peak / 2**30:.1f} GiB "
           f"of {torch.cuda.mem_get_info()[1] / 2**30:.0f}", flush=True)
     # ---- size-independent properties (tests/test_configs45.py:74-118) at this size
-    assert ids.shape == (n,) and ids.min() == 1
-    lv = tree._leaves()
-    k = lv["ids"].size
-    assert int(ids.max()) == k
-    sizes = np.bincount(ids.astype(np.int64), minlength=k + 1)[1:]
-    order = tree._leaf_order(True)
-    assert (sizes == lv["n"][order].astype(np.int64)).all() and (np.diff(sizes) <= 0).all()
-    srt = np.sort(lv["members"])
-    assert srt.size == n and srt[0] == 0 and srt[-1] == n - 1 and (np.diff(srt) == 1).all()
-    del srt
-    print(f"clusters {k}: largest {int(sizes[0])}, singletons {int((sizes == 1).sum())}; partition of 0..{n - 1}: ok", flush=True)
-    # column sums of the final cluster features, gathered on the device a slab of leaves at a time
-    total = torch.zeros(2048, dtype=torch.int64, device=dev)
-    total_n = 0
-    groups = tree._group_positions(order)
-    for name, pos in groups.items():
-        width = np.dtype(name).itemsize
-        step = max(1, (1 << 30) // (2049 * width))
-        for lo in range(0, pos.size, step):
-            p = pos[lo:lo + step]
-            ones = lv["n"][p] == 1
-            n_tail = int(ones.size if ones.all() else np.argmax(~ones[::-1])) if width == 1 else 0
-            tab = tree._engine.gather_buffers(p, width, device_out=True, n_tail=n_tail)
-            if tab.n_head:
-                v = tab.raw.view(tab.n_head, 2049, width)
-                vals = v[:, :, 0].to(torch.int64)
-                for b in range(1, width):
-                    vals += v[:, :, b].to(torch.int64) << (8 * b)
-                total += vals[:, :-1].sum(dim=0)
-                total_n += int(vals[:, -1].sum())
-                del v, vals
-            if tab.tail is not None:
-                for q in range(0, tab.n_tail, 250_000):
-                    bits = (tab.tail[q:q + 250_000, :, None] >> shifts) & 1
-                    total += bits.view(-1, 2048).sum(dim=0, dtype=torch.int64)
-                total_n += tab.n_tail
-            del tab
-    assert total_n == n, (total_n, n)
-    assert torch.equal(total, want)
+    from props import check_clustering
+
+    cs = check_clustering(tree, n, want, ids)
+    print(f"clusters {cs['clusters']}: largest {cs['largest']}, singletons {cs['singletons']}; partition of 0..{n - 1}: ok", flush=True)
     print("cluster-feature column sums == column sums of all fingerprints: ok", flush=True)
+    mem = tree._engine.memory()
+    print(f"final tree memory: node pools {int(mem[0]) / 1e9:.2f} GB ({int(mem[1]) / 1e9:.2f} GB used = {int(mem[1]) / 1e9 / (n / 1e6):.3f} GB per million "
+          f"fingerprints), cluster-feature pools {int(mem[2]) / 1e9:.2f} GB, peak of this tree's allocations {int(mem[3]) / 1e9:.2f} GB; "
+          f"{int(mem[4])} compactions, last one: {int(mem[5])} nodes sealed / {int(mem[6])} at full capacity; {int(mem[7])} sealed nodes thawed", flush=True)
     st = tree._engine.stats()
     print(f"final tree: stats {st.tolist()}", flush=True)
     dist.destroy_process_group()

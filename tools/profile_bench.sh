@@ -46,6 +46,7 @@ for name in ("pmc_fetch", "pmc_write"):
                     rec["k1_" + ("fetch" if c == "FETCH_SIZE" else "write") + "_kb_per_dispatch"] = v / max(n, 1)
 import json
 rec["n_fps"] = int(sys.argv[2])
+rec["fits"] = 2  # the profiled command: --steps 1 --warmup 0 + bench.py's end-to-end step (fit + labels)
 sys.path.insert(0, os.environ.get("BB_ROOT", "."))
 try:
     import bench
