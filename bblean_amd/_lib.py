@@ -34,6 +34,7 @@ _PROTOTYPES = {
     "bbh_device_count": (_int, []),
     "bbh_device_info": (_int, [_int, C.c_char_p, C.c_size_t]),
     "bbh_trim_cache": (_int, []),
+    "bbh_set_memory_pressure_callback": (_int, [_vp]),
     "bbh_popcount_rows": (_int, [_vp, _i64, _i64, _i64, _vp, _vp]),
     "bbh_jt_arr_vec": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "bbh_jt_best_match": (_int, [_vp, _i64, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
@@ -96,7 +97,30 @@ def load() -> C.CDLL:
         fn.restype = res
         fn.argtypes = args
     _LIB = lib
+    _register_pressure_callback(lib)
     return lib
+
+
+_PRESSURE_CB = None  # (kept alive: the library holds the raw function pointer)
+
+
+def _register_pressure_callback(lib: C.CDLL) -> None:
+    r"""When a device allocation of the library fails it asks the host side to let go of what it caches on the device:
+    torch's caching allocator keeps freed tensors (round tables of gigabytes) that `hipMalloc` then cannot have."""
+    global _PRESSURE_CB
+
+    def _release() -> None:
+        try:
+            import sys
+
+            torch = sys.modules.get("torch")
+            if torch is not None and torch.cuda.is_initialized():
+                torch.cuda.empty_cache()
+        except Exception:
+            pass
+
+    _PRESSURE_CB = C.CFUNCTYPE(None)(_release)
+    lib.bbh_set_memory_pressure_callback(C.cast(_PRESSURE_CB, C.c_void_p))
 
 
 class BBHipError(RuntimeError):

@@ -745,7 +745,16 @@ class BitBirch:
             else:
                 fps = np.asarray(X)[arr_idxs]
             if dev_ok:
-                big_rows.append(fps)  # packed rows: they go into the table's singleton tail as they are
+                # packed rows: they go into the table's singleton tail as they are - which they must be: uint8, F / 8 columns
+                # (the host path normalises through unpack_fingerprints; here a wrong width would only surface as an engine
+                # error about row bytes much later)
+                if not hasattr(fps, "data_ptr"):
+                    fps = np.ascontiguousarray(fps)
+                    if fps.dtype != np.uint8:
+                        fps = fps.astype(np.uint8)
+                if fps.ndim != 2 or int(fps.shape[1]) != F // 8 or (hasattr(fps, "data_ptr") and str(fps.dtype) != "torch.uint8"):
+                    raise ValueError(f"packed fingerprints of {F} features must be uint8 rows of {F // 8} bytes, got {tuple(fps.shape)} {fps.dtype}")
+                big_rows.append(fps)
                 big_ids.append(mol_idxs)
                 continue
             fps = np.asarray(fps)
@@ -812,8 +821,14 @@ class BitBirch:
         (reference bitbirch.py:1187-1214)."""
         self._require_init()
         self.delete_internal_nodes()
-        # (the tables stay in HBM when the engine can do that: gathered there, re-inserted from there)
-        bufs, mols = self._refine_tables(X, initial_mol, input_is_packed, n_largest, device=True)
+        # (the tables stay in HBM when the engine can do that: gathered there, re-inserted from there - next to the old tree's
+        # pools, which reset() keeps; when HBM does not hold both, the tables take the reference's way through host memory)
+        try:
+            bufs, mols = self._refine_tables(X, initial_mol, input_is_packed, n_largest, device=True)
+        except Exception as exc:
+            if not _is_out_of_memory(exc):
+                raise
+            bufs, mols = self._refine_tables(X, initial_mol, input_is_packed, n_largest, device=False)
         self.reset()
         for name in bufs:
             self._fit_buffers(bufs[name], reinsert_index_seqs=mols[name])
@@ -847,7 +862,12 @@ class BitBirch:
                 random.seed(seed)
                 random.shuffle(perm)
                 order = order[np.asarray(perm, dtype=np.int64)]
-            bufs, mols = self._bf_tables(order, device=True)
+            try:
+                bufs, mols = self._bf_tables(order, device=True)
+            except Exception as exc:
+                if not _is_out_of_memory(exc):
+                    raise
+                bufs, mols = self._bf_tables(order, device=False)
             self.reset()
             self.threshold += extra_threshold
             for name in bufs:
@@ -908,6 +928,15 @@ class BitBirch:
         if self.tolerance is not None:
             parts.append(f"tolerance={self.tolerance}")
         return f"{self.__class__.__name__}({', '.join(parts)})"
+
+
+def _is_out_of_memory(exc: BaseException) -> bool:
+    r"""A device allocation that failed: torch's OutOfMemoryError, the engine's MemoryError (BBH_ERR_CAPACITY) or a HIP error
+    that says so."""
+    if isinstance(exc, MemoryError):
+        return True
+    name = type(exc).__name__
+    return "OutOfMemory" in name or "out of memory" in str(exc).lower()
 
 
 def fit_concurrently(

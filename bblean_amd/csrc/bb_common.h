@@ -62,12 +62,13 @@ int ensure_device();  // picks device 0 lazily, checks it is gfx950
 // Caching device allocator.  hipFree synchronises the device and hipMalloc of small blocks
 // costs tens of microseconds; a tree owns eight pools that are re-allocated as it grows and a
 // multiround round creates hundreds of trees, so blocks are recycled by size class instead of
-// being returned to the driver (bbh_trim_cache releases them; at most BBHIP_CACHE_MB, default
-// 16 GiB, are retained per process).
+// being returned to the driver (bbh_trim_cache releases them): blocks of up to 64 MiB, at most BBHIP_CACHE_MB (default 4 GiB)
+// per process; larger blocks go straight back to the driver.
 // ---------------------------------------------------------------------------------------
 hipError_t dev_alloc(void** p, size_t bytes);
 void dev_free(void* p);
 void dev_trim();
+void set_pressure_callback(void (*fn)(void));  // called when hipMalloc fails, before the one retry (bbh_set_memory_pressure_callback)
 template <typename T>
 inline hipError_t dev_alloc(T** p, size_t bytes) { return dev_alloc((void**)p, bytes); }
 

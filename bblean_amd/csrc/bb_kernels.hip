@@ -6,6 +6,8 @@
 // bblean/csrc/similarity.cpp (cited at each function and in include/bbhip.h).
 #include "bb_common.h"
 
+#include <atomic>
+
 #include <cmath>
 
 using namespace bbd;
@@ -60,16 +62,26 @@ struct DevCache {
     std::map<std::pair<int, size_t>, std::vector<void*>> free_blocks;  // (device, class bytes) -> blocks
     std::map<void*, std::pair<int, size_t>> live;                      // block -> (device, class bytes)
     size_t cached = 0;
-    size_t limit = 16ull << 30;
+    size_t limit = 4ull << 30;
+    // Only blocks up to kMaxCached are recycled: the pools of a small tree (a multiround round creates hundreds of them).  A
+    // tree of millions of rows frees blocks of gigabytes whose exact size nobody asks for again; retained, they filled the
+    // cache to its limit - after which every small block went back to the driver (hipFree synchronises) and came from it
+    // again (hipMalloc): bench.py's 512 concurrent shard trees took 0.34 s instead of 0.05 s once a 10 M-row tree had been
+    // built and dropped in the same process (round 4's `concurrent_shards` regression) - and kept up to 16 GiB of HBM from
+    // whoever needed it next.
+    static constexpr size_t kMaxCached = 64ull << 20;
     DevCache() {
         if (const char* e = getenv("BBHIP_CACHE_MB")) limit = (size_t)atoll(e) << 20;
     }
     static size_t size_class(size_t bytes) {
         if (bytes <= 512) return 512;
-        if (bytes <= (1u << 20)) {
+        if (bytes <= kMaxCached) {
+            // powers of two in four steps (1, 1.25, 1.5, 1.75 x 2^k): at most a quarter wasted, sizes meet again
             size_t c = 512;
-            while (c < bytes) c <<= 1;
-            return c;
+            while (c * 2 < bytes) c <<= 1;
+            if (c >= bytes) return c;
+            const size_t q = c / 4;
+            return c + (bytes - c + q - 1) / q * q;
         }
         const size_t mb = 1u << 20;
         return (bytes + mb - 1) / mb * mb;
@@ -80,6 +92,9 @@ DevCache& dev_cache() {
     return *c;
 }
 }  // namespace
+
+static std::atomic<void (*)(void)> g_pressure_cb{nullptr};
+void set_pressure_callback(void (*fn)(void)) { g_pressure_cb.store(fn); }
 
 hipError_t dev_alloc(void** p, size_t bytes) {
     DevCache& c = dev_cache();
@@ -99,9 +114,10 @@ hipError_t dev_alloc(void** p, size_t bytes) {
         }
     }
     e = hipMalloc(p, cls);
-    if (e != hipSuccess) {  // give the cached blocks back to the driver and retry once
+    if (e != hipSuccess) {  // give the cached blocks back to the driver - ours and the host side's - and retry once
         (void)hipGetLastError();
         dev_trim();
+        if (void (*cb)(void) = g_pressure_cb.load()) cb();
         e = hipMalloc(p, cls);
         if (e != hipSuccess) return e;
     }
@@ -119,7 +135,7 @@ void dev_free(void* p) {
         if (it != c.live.end()) {
             const std::pair<int, size_t> key = it->second;
             c.live.erase(it);
-            if (c.cached + key.second <= c.limit) {
+            if (key.second <= DevCache::kMaxCached && c.cached + key.second <= c.limit) {
                 c.free_blocks[key].push_back(p);
                 c.cached += key.second;
                 return;
@@ -902,6 +918,11 @@ extern "C" int bbh_most_dissimilar(const uint8_t* Y, int64_t n, int64_t nbytes, 
 // misc C ABI
 // =======================================================================================
 extern "C" const char* bbh_last_error(void) { return bb::g_err; }
+
+extern "C" int bbh_set_memory_pressure_callback(void (*fn)(void)) {
+    bb::set_pressure_callback(fn);
+    return BBH_OK;
+}
 
 extern "C" int bbh_trim_cache(void) {
     bb::dev_trim();

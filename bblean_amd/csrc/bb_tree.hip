@@ -149,6 +149,7 @@ struct TreeDev {
     long long processed;
     int32_t stop_reason;
     int32_t audit;  // (phase-timer build of the pipelined kernel, BBHIP_PIPE_AUDIT=1) compare the LDS state with HBM at every run end
+    uint32_t giveup_line;  // STOP_INTERNAL: the line of bb_tree_pipe.inc where a bounded wait gave up
 };
 
 // LDS layout: byte offsets from the start of the dynamic shared segment
@@ -1254,7 +1255,18 @@ __device__ __forceinline__ void split_node(const KCt& k, const Elem& el, int& re
     // 6. ids for the new node and the two tracking BitFeatures (always cf32): every thread
     //    keeps the (uniform) allocation counters in registers
     const uint32_t node1 = alloc_n<SUB>(k, cN, gctr + C_NODES, k.nblk, 14);  // (a full-capacity node)
-    const uint32_t slotA_i = alloc_n<SUB>(k, c32, gctr + C_N32, 2, 15), slotB_i = slotA_i + 1;
+    // (the row that tracked nd goes on tracking node1 and KEEPS its cf32 slot: the old sums are read - by_difference, below,
+    // every thread its own features - before the new ones are written to the same place.  Until round 5 both halves got new
+    // slots and the old one was abandoned: half of the cf32 pool of a large tree was such garbage, 13 GB of 24 GB at 20 M
+    // S-ecfp rows.)
+    uint32_t slotA_i, slotB_i;
+    if (trk_slot != NONE) {
+        slotA_i = trk_slot & 0x3FFFFFFFu;
+        slotB_i = alloc_n<SUB>(k, c32, gctr + C_N32, 1, 15);
+    } else {
+        slotA_i = alloc_n<SUB>(k, c32, gctr + C_N32, 2, 15);
+        slotB_i = slotA_i + 1;
+    }
     const uint32_t was_leaf = uni(hold.y) & HW_LEAF, prev_leaf = uni(hold.z);
     if (was_leaf && prev_leaf == NONE) {
         if constexpr (SUB) { if (tid == 0) stg<uint32_t>(gctr + C_FIRST_LEAF, node1); }
@@ -2187,16 +2199,19 @@ static const FastKernel kFastKernels[] = {  // (most specific first)
 struct PipeKernel {
     int bf, crit, ml;  // ml: the multi-level instance (several exact internal levels, pipe_router_ml)
     void (*fn)(TreeDev*);
+    void (*fn_prof)(TreeDev*);  // the phase-timer / run-end-audit instance (BBHIP_PIPE_PHASES, BBHIP_PIPE_AUDIT): every entry has one
     uint32_t lds;
 };
+#define BB_PIPE_ENTRY(BF, CRIT, ML) {BF, CRIT, ML, k_tree_pipe<KP<BF, CRIT, ML>>, k_tree_pipe<KP<BF, CRIT, ML>, true>, pipe_layout(BF, ML).total}
 static const PipeKernel kPipeKernels[] = {
-    {50, BBH_CRIT_DIAMETER, 0, k_tree_pipe<KP<50, BBH_CRIT_DIAMETER>>, pipe_layout(50).total},
-    {50, BBH_CRIT_TOL_DIAMETER, 0, k_tree_pipe<KP<50, BBH_CRIT_TOL_DIAMETER>>, pipe_layout(50).total},
-    {254, BBH_CRIT_DIAMETER, 0, k_tree_pipe<KP<254, BBH_CRIT_DIAMETER>>, pipe_layout(254).total},
-    {254, BBH_CRIT_TOL_DIAMETER, 0, k_tree_pipe<KP<254, BBH_CRIT_TOL_DIAMETER>>, pipe_layout(254).total},
-    {50, BBH_CRIT_DIAMETER, 1, k_tree_pipe<KP<50, BBH_CRIT_DIAMETER, 1>>, pipe_layout(50, 1).total},
-    {50, BBH_CRIT_TOL_DIAMETER, 1, k_tree_pipe<KP<50, BBH_CRIT_TOL_DIAMETER, 1>>, pipe_layout(50, 1).total},
+    BB_PIPE_ENTRY(50, BBH_CRIT_DIAMETER, 0),
+    BB_PIPE_ENTRY(50, BBH_CRIT_TOL_DIAMETER, 0),
+    BB_PIPE_ENTRY(254, BBH_CRIT_DIAMETER, 0),
+    BB_PIPE_ENTRY(254, BBH_CRIT_TOL_DIAMETER, 0),
+    BB_PIPE_ENTRY(50, BBH_CRIT_DIAMETER, 1),
+    BB_PIPE_ENTRY(50, BBH_CRIT_TOL_DIAMETER, 1),
 };
+#undef BB_PIPE_ENTRY
 
 // uint8 BitFeature buffers with n_samples == 1 are plain fingerprints in unpacked form (ls in {0, 1}):
 // pack them (MSB first, np.packbits order) so that they take the fingerprint path of the kernel.
@@ -2505,9 +2520,11 @@ static bool tiny_pools() {  // (read on every call: tests switch it on and off i
 }
 // a pool that has to grow grows by at least half (a tree fed in 64 MiB slabs asked for a slightly larger pool with every
 // slab, i.e. copied all of it every time); `hint` is what the caller expects to need
-static uint32_t grow_target(uint32_t cap, uint32_t want) {
+static uint32_t grow_target(uint32_t cap, uint32_t want, size_t elem_bytes = 0) {
     if (tiny_pools()) return want;
-    const uint64_t geo = (uint64_t)cap + cap / 2;
+    // (a pool of gigabytes grows by an eighth: while it is copied it exists twice, and at 100 M rows the cf32 pool's "half as
+    // much again" was 90 GB next to 60)
+    const uint64_t geo = (uint64_t)cap + ((uint64_t)cap * elem_bytes > (4ull << 30) ? cap / 8 : cap / 2);
     return (uint32_t)std::min<uint64_t>(0x3FFFFFFFull, std::max<uint64_t>(want, geo));
 }
 
@@ -2521,6 +2538,10 @@ static uint32_t fit_to_memory(uint32_t want, uint32_t floor_elems, uint32_t cap,
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return want; }
     // (the copying growth holds the old pool until the new one is filled: only the free memory counts)
     const size_t room = (size_t)((double)free_b * 0.9) / std::max<size_t>(elem_bytes, 1);
+    // (a pool that the free memory only lets grow by the floor - a few dozen elements - would be copied whole every
+    // few dozen insertions: when less than a sixteenth more than the pool holds fits, the growth is refused - the allocation
+    // of `want` fails with "out of memory", which is the truth - instead of crawling)
+    if (room < (uint64_t)cap + std::max<uint64_t>(cap / 16, floor_elems > cap ? floor_elems - cap : 0)) return want;
     const uint64_t most = std::max<uint64_t>(floor_elems, std::min<uint64_t>(want, room));
     return (uint32_t)std::min<uint64_t>(most, 0x3FFFFFFFull);
 }
@@ -2710,15 +2731,15 @@ int grow_cf(bbh_tree* t, int tier, uint32_t want) {
     TreeDev& h = t->h;
     const size_t F = (size_t)h.F;
     if (tier == 0 && want > h.cap8) {
-        want = fit_to_memory(grow_target(h.cap8, want), std::max<uint32_t>(clamp30((uint64_t)h.ctr[C_N8] + 2 * (uint64_t)h.ctr[C_DEPTH] + 64), h.cap8 + 1), h.cap8, F * 1);
+        want = fit_to_memory(grow_target(h.cap8, want, F), std::max<uint32_t>(clamp30((uint64_t)h.ctr[C_N8] + 2 * (uint64_t)h.ctr[C_DEPTH] + 64), h.cap8 + 1), h.cap8, F * 1);
         BB_TRY(grow_pool(h.cf8, (size_t)std::min(h.cap8, h.ctr[C_N8]) * F, (size_t)want * F));
         h.cap8 = want;
     } else if (tier == 1 && want > h.cap16) {
-        want = fit_to_memory(grow_target(h.cap16, want), std::max<uint32_t>(clamp30((uint64_t)h.ctr[C_N16] + 2 * (uint64_t)h.ctr[C_DEPTH] + 64), h.cap16 + 1), h.cap16, F * 2);
+        want = fit_to_memory(grow_target(h.cap16, want, F * 2), std::max<uint32_t>(clamp30((uint64_t)h.ctr[C_N16] + 2 * (uint64_t)h.ctr[C_DEPTH] + 64), h.cap16 + 1), h.cap16, F * 2);
         BB_TRY(grow_pool(h.cf16, (size_t)std::min(h.cap16, h.ctr[C_N16]) * F, (size_t)want * F));
         h.cap16 = want;
     } else if (tier == 2 && want > h.cap32) {
-        want = fit_to_memory(grow_target(h.cap32, want), std::max<uint32_t>(clamp30((uint64_t)h.ctr[C_N32] + 2 * (uint64_t)h.ctr[C_DEPTH] + 64), h.cap32 + 1), h.cap32, F * 4);
+        want = fit_to_memory(grow_target(h.cap32, want, F * 4), std::max<uint32_t>(clamp30((uint64_t)h.ctr[C_N32] + 2 * (uint64_t)h.ctr[C_DEPTH] + 64), h.cap32 + 1), h.cap32, F * 4);
         BB_TRY(grow_pool(h.cf32, (size_t)std::min(h.cap32, h.ctr[C_N32]) * F, (size_t)want * F));
         h.cap32 = want;
     }
@@ -2740,13 +2761,14 @@ int init_empty(bbh_tree* t) {
     TreeDev& h = t->h;
     std::memset(h.ctr, 0, sizeof(h.ctr));
     const uint32_t nblk = node_blocks((uint32_t)h.bf + 1);
-    BB_TRY(grow_nodes(t, std::max<uint32_t>(h.cap_nodes, 64 * nblk)));
+    const bool fresh_pools = h.cap_nodes == 0;  // (allocated - and their headers zeroed - right here)
+    BB_TRY(grow_nodes(t, std::max<uint32_t>(h.cap_nodes, (tiny_pools() ? 4 : 64) * nblk)));
     BB_TRY(grow_cf(t, 0, std::max<uint32_t>(h.cap8, 1024)));
     BB_TRY(grow_cf(t, 1, std::max<uint32_t>(h.cap16, 64)));
     BB_TRY(grow_cf(t, 2, std::max<uint32_t>(h.cap32, 256)));
     NodeHdr root;
     root.len = 0; root.leaf = hw_make(1u, (uint32_t)h.bf + 1); root.prev = NONE; root.next = NONE;
-    BB_HIP(hipMemset(h.node_hdr, 0, ((size_t)h.cap_nodes + 1) * sizeof(NodeHdr)));  // (a reset tree: no header of the old one survives)
+    if (!fresh_pools) BB_HIP(hipMemset(h.node_hdr, 0, ((size_t)h.cap_nodes + 1) * sizeof(NodeHdr)));  // (a reset tree: no header of the old one survives)
     BB_HIP(hipMemcpy(h.node_hdr, &root, sizeof(root), hipMemcpyHostToDevice));
     h.ctr[C_NODES] = nblk;
     h.ctr[C_N8] = 1;  // (slot 0 of the uint8 pool is SLOT_LAZY8: never a BitFeature's)
@@ -2819,11 +2841,10 @@ int configure(bbh_tree* t, int32_t bf, int32_t n_features) {
                     BB_HIP(hipFuncSetAttribute((const void*)fk.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fk.lds));
                 BB_HIP(hipFuncSetAttribute((const void*)k_tree_fast<KF50P, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast_layout(50).total));
                 BB_HIP(hipFuncSetAttribute((const void*)k_tree_fast<KF254P, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast_layout(254).total));
-                for (const PipeKernel& pk : kPipeKernels)
+                for (const PipeKernel& pk : kPipeKernels) {
                     BB_HIP(hipFuncSetAttribute((const void*)pk.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pk.lds));
-                BB_HIP(hipFuncSetAttribute((const void*)k_tree_pipe<KP<50, BBH_CRIT_DIAMETER>, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pipe_layout(50).total));
-                BB_HIP(hipFuncSetAttribute((const void*)k_tree_pipe<KP<50, BBH_CRIT_DIAMETER, 1>, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pipe_layout(50, 1).total));
-                BB_HIP(hipFuncSetAttribute((const void*)k_tree_pipe<KP<254, BBH_CRIT_DIAMETER>, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pipe_layout(254).total));
+                    BB_HIP(hipFuncSetAttribute((const void*)pk.fn_prof, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pk.lds));
+                }
             } else {
                 return bb::fail(BBH_ERR_NO_DEVICE, "device %d offers %d bytes of LDS per workgroup, the tree kernels need %u", t->device, cap,
                                 pipe_layout(254).total);
@@ -3053,14 +3074,9 @@ int run_insert_multi(std::vector<Job>& jobs, hipStream_t s) {
                     e = hipMemcpyAsync(dptr, harr.data(), active.size() * sizeof(TreeDev), hipMemcpyHostToDevice, s);
                     if (e != hipSuccess) { rc = bb::fail(BBH_ERR_HIP, "H2D: %s", hipGetErrorString(e)); break; }
                 }
-                if (pipe_phases && pk->crit == BBH_CRIT_DIAMETER && pk->bf == 50 && pk->ml)
-                    hipLaunchKernelGGL((k_tree_pipe<KP<50, BBH_CRIT_DIAMETER, 1>, true>), grid, block, pk->lds, s, dptr);
-                else if (pipe_phases && pk->crit == BBH_CRIT_DIAMETER && pk->bf == 50)
-                    hipLaunchKernelGGL((k_tree_pipe<KP<50, BBH_CRIT_DIAMETER>, true>), grid, block, pk->lds, s, dptr);
-                else if (pipe_phases && pk->crit == BBH_CRIT_DIAMETER)
-                    hipLaunchKernelGGL((k_tree_pipe<KP<254, BBH_CRIT_DIAMETER>, true>), grid, block, pk->lds, s, dptr);
-                else
-                    hipLaunchKernelGGL(pk->fn, grid, block, pk->lds, s, dptr);
+                // (every instance has its phase-timer / audit twin - ADVICE r4: tolerance-diameter trees used to run unaudited
+                // under BBHIP_PIPE_AUDIT while bbh_tree_stats reported "no difference")
+                hipLaunchKernelGGL(pipe_phases ? pk->fn_prof : pk->fn, grid, block, pk->lds, s, dptr);
             } else if (fk != nullptr && prof_phases && f_packed) {
                 log_kernel = "fast+phases";
                 if (all50) hipLaunchKernelGGL((k_tree_fast<KF50P, true>), grid, block, fk->lds, s, dptr);
@@ -3148,7 +3164,7 @@ int run_insert_multi(std::vector<Job>& jobs, hipStream_t s) {
             uint64_t uleft_for_nodes = 0;
             auto more = [&](uint32_t used, uint32_t cap, uint64_t expect) -> uint32_t {
                 if (tiny_pools()) return clamp30((uint64_t)cap + 8 + 2 * (uint64_t)h.ctr[C_DEPTH]);  // (one insertion's worst case fits)
-                return clamp30(std::max<uint64_t>((uint64_t)cap + cap / 2, (uint64_t)used + expect));
+                return clamp30(std::max<uint64_t>((uint64_t)cap + 1, (uint64_t)used + expect));  // (grow_cf takes the larger of this and its geometric step)
             };
             const uint64_t nblk = node_blocks((uint32_t)h.bf + 1);
             // (nodes: blocks; a pool that is compacted on the way - grow_nodes - takes `want - used` as the room asked for)
@@ -3180,10 +3196,7 @@ int run_insert_multi(std::vector<Job>& jobs, hipStream_t s) {
                 case STOP_PIPE_NEEDS_ML: t->pipe_ml = true; break;  // relaunched at once, with the multi-level instance
                 case STOP_PIPE_PREFERS_SL: t->pipe_ml = false; break;  // ... and back (after a stint of >= PIPE_ML_STINT elements)
                 case STOP_INTERNAL: {
-                    unsigned int line = 0;
-                    (void)hipMemcpyFromSymbol(&line, HIP_SYMBOL(g_pipe_giveup_line), sizeof(line));
-                    const unsigned int zero = 0;
-                    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_pipe_giveup_line), &zero, sizeof(zero));
+                    const unsigned int line = back.giveup_line;
                     rc = bb::fail(BBH_ERR_HIP, "pipelined kernel: a wait gave up (internal error; first at bb_tree_pipe.inc:%u)", line);
                     break;
                 }

@@ -352,6 +352,12 @@ def _entry_key(label: str, name: str) -> str:
     return f"label-{label}-{name.replace('8', '08')}"
 
 
+def _tail_row_bytes(cols: int) -> int:
+    r"""Bytes of one packed singleton row of a table of `cols` = n_features + 1 columns: what the sender ships
+    (engine.nbytes = ceil(n_features / 8)) and what every receive buffer is sized with - ONE place for both."""
+    return (cols - 1 + 7) // 8
+
+
 class _Exchange:
     r"""Moves BitFeature tables between ranks for the next round: every table goes to the ONE rank that
     merges it (point-to-point, `batch_isend_irecv`), never to the others.
@@ -446,7 +452,7 @@ class _Exchange:
                 kh = k - ntail  # rows [kh, k): the packed singleton tail (a chunk lies on one side of kh)
                 a = 0
                 while a < k or (k == 0 and a == 0):
-                    row_bytes = cols * np.dtype(name).itemsize if a < kh or k == 0 else (cols - 1) // 8
+                    row_bytes = cols * np.dtype(name).itemsize if a < kh or k == 0 else _tail_row_bytes(cols)
                     per = max(1, budget_bytes // max(row_bytes, 1))
                     b_ = min(kh if a < kh else k, a + per)
                     nb = (b_ - a) * row_bytes
@@ -494,7 +500,7 @@ class _Exchange:
                                 self.bytes_sent += int(t.numel())
                         keep.append(parts)
                     elif dst == rank:
-                        tb = torch.empty((b_ - a, (cols - 1) // 8 if in_tail else cols * item), dtype=torch.uint8, device=self.tdev)
+                        tb = torch.empty((b_ - a, _tail_row_bytes(cols) if in_tail else cols * item), dtype=torch.uint8, device=self.tdev)
                         bufs = [tb]
                         if first:
                             bufs += [torch.empty(k * 8, dtype=torch.uint8, device=self.tdev),
@@ -529,6 +535,7 @@ class _Exchange:
                         else:
                             part = DevTable(tb, np.dtype(name).itemsize)
                     else:
+                        assert not recv_cols.get((b, pos), 0), "a chunk of a packed singleton tail reached a rank that keeps its tables on the host"
                         part = tb.numpy().view(np.dtype(name)).reshape(b_ - a, -1)
                 else:
                     part = payload
@@ -585,7 +592,7 @@ class _Exchange:
                             self.bytes_sent += int(t.numel())
                 elif dst == rank:
                     tb = torch.empty((k - ntail, cols * item), dtype=torch.uint8, device=self.tdev)
-                    tt = torch.empty((ntail, (cols - 1) // 8), dtype=torch.uint8, device=self.tdev)  # the packed singleton tail
+                    tt = torch.empty((ntail, _tail_row_bytes(cols)), dtype=torch.uint8, device=self.tdev)  # the packed singleton tail
                     cb = torch.empty(k * 8, dtype=torch.uint8, device=self.tdev)
                     ib = torch.empty(nids * 8, dtype=torch.uint8, device=self.tdev)
                     for t in (tb, tt, cb, ib):
@@ -607,6 +614,9 @@ class _Exchange:
                 table = DevTable(tb if tb.device == self.table_dev else tb.to(self.table_dev), np.dtype(name).itemsize,
                                  tt if tt.device == self.table_dev else tt.to(self.table_dev))
             else:
+                # (a host table is the reference's full-width array: a sender only ships a packed tail from a device table, and
+                # all ranks of a job share the choice)
+                assert tt.numel() == 0, "a table with a packed singleton tail reached a rank that keeps its tables on the host"
                 table = tb.numpy().view(np.dtype(name)).reshape(k, cols)
             mine_out.setdefault(b, []).append((pos, (lab, name, table, _IndexLists(cnt_np, ids_np))))
             recv_into[(b, pos)] = None  # (the staging tensors of the member lists are not kept next to the tables)

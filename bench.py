@@ -353,9 +353,10 @@ def parse() -> argparse.Namespace:
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--n-fps", type=int, default=None,
-                    help="rows per GPU (default 1 000 000 at N=1, 250 000 per GPU at N>1)")
-    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="fake")
-    ap.add_argument("--bf", type=int, default=50)
+                    help="rows per GPU (default 1 000 000 at N=1, 2 000 000 per GPU at N>1; BASELINE configs[3] states 12 500 000)")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default=None,
+                    help="default: fake at N=1 (BASELINE configs[1]), ecfp at N>1 (configs[3])")
+    ap.add_argument("--bf", type=int, default=None, help="default: 50 at N=1 (configs[1]), 254 at N>1 (the CLI default, configs[3])")
     ap.add_argument("--threshold", type=float, default=None)
     ap.add_argument("--cpu-sample", type=int, default=None, help="rows of the CPU baseline (default: all)")
     ap.add_argument("--no-cpu", action="store_true")
@@ -396,10 +397,15 @@ def main() -> None:
     if world != args.gpus:
         sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
                  f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...)")
+    multi = not (world == 1 and not args.distributed)
+    if args.workload is None:
+        args.workload = "ecfp" if multi else "fake"
+    if args.bf is None:
+        args.bf = 254 if multi else 50
     if args.threshold is None:
         args.threshold = WORKLOADS[args.workload][1]
     if args.n_fps is None:
-        args.n_fps = 1_000_000 if world == 1 else 250_000
+        args.n_fps = 2_000_000 if multi else 1_000_000
     if world == 1 and not args.distributed:
         single_gpu(args)
     else:
@@ -475,11 +481,14 @@ def multi_gpu(args: argparse.Namespace, world: int) -> None:
 
         import numpy as np
 
+        # (a bounded sample: the first 100 000 rows of every rank's shard - 10-30 s of host work; the whole job's merge rounds are
+        # sequential on the CPU too and would take ten minutes at 2 M rows per shard)
+        msamp = min(n, 100_000)
         with tempfile.TemporaryDirectory() as d:
             names = []
             for r in range(world):
                 f = Path(d) / f"fps.{r:05d}.npy"
-                np.save(f, gen(n, 1000 + r, dev).cpu().numpy())
+                np.save(f, gen(n, 1000 + r, dev)[:msamp].cpu().numpy())
                 names.append(f)
             cpu_mr = cpu_multiround_baseline(names, args.bf, args.threshold)
     if rank == 0:
@@ -500,7 +509,8 @@ def multi_gpu(args: argparse.Namespace, world: int) -> None:
             "dtype": "u8",
             "data": "synthetic",
             "config": {
-                "workload": f"multiround over {world} GPUs: {world} shards x {n} synthetic 2048-bit packed fingerprints "
+                "workload": f"BASELINE configs[3] (multiround, one shard per GPU) at {n} rows per shard (stated: 12 500 000 per shard = "
+                            f"--n-fps 12500000; tools/config45.py runs that size on one GPU): multiround over {world} GPUs: {world} shards x {n} synthetic 2048-bit packed fingerprints "
                             f"({WORKLOADS[args.workload][2]}), one shard per GPU resident in HBM, threshold={args.threshold}, "
                             f"branching_factor={args.bf}, reference defaults otherwise (diameter, full refinement, one merge "
                             "round in bins of 10, tolerance-diameter merges); timed region = run_multiround_distributed "

@@ -54,6 +54,11 @@ int bbh_device_info(int device, char* buf, size_t buflen);
  * reference counterpart: NumPy's allocator plays this role there. */
 int bbh_trim_cache(void);
 
+/* A function the library calls when a device allocation fails, before it tries once more: the host side hands over what
+ * IT caches on the device (the Python shim registers torch.cuda.empty_cache - a caching tensor allocator keeps freed round
+ * tables of gigabytes that the driver then cannot give to a growing tree pool).  NULL removes it. */
+int bbh_set_memory_pressure_callback(void (*fn)(void));
+
 /* ---------------------------------------------------------------------------------- */
 /* Stateless kernels -- one per pybind11 binding of similarity.cpp:473-521             */
 /* ---------------------------------------------------------------------------------- */

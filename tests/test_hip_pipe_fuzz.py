@@ -260,3 +260,13 @@ def test_pipe_run_end_audit():
     assert line and int(line[-1].split()[3]) > 100, r.stderr[-2000:]  # hundreds of runs ended and were audited
     r = subprocess.run([sys.executable, "-c", code], env=dict(env, BBHIP_PIPE_AUDIT="corrupt"), capture_output=True, text=True, timeout=600)
     assert r.returncode != 0 and "run-end audit" in r.stderr, r.stderr[-2000:]
+    # tolerance-diameter trees (refinement, the merge rounds) run audited instances too (until round 5 only the diameter
+    # instances had one: a test "under the audit" could pass without a single slot audited)
+    code_tol = code.replace("merge_criterion='diameter'", "merge_criterion='tolerance-diameter', tolerance=0.05")
+    assert code_tol != code
+    r = subprocess.run([sys.executable, "-c", code_tol], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stderr.splitlines() if "[bbhip pipe audit]" in ln]
+    assert line and int(line[-1].split()[3]) > 100, r.stderr[-2000:]
+    r = subprocess.run([sys.executable, "-c", code_tol], env=dict(env, BBHIP_PIPE_AUDIT="corrupt"), capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "run-end audit" in r.stderr, r.stderr[-2000:]
