@@ -2534,6 +2534,9 @@ uint32_t clamp30(uint64_t v) { return (uint32_t)std::min<uint64_t>(0x3FFFFFFFull
 // out of memory: beyond `floor_elems` (what is needed now) the pool only takes what the driver reports free, less a tenth
 static uint32_t fit_to_memory(uint32_t want, uint32_t floor_elems, uint32_t cap, size_t elem_bytes) {
     if (want <= floor_elems) return want;
+    // (hipMemGetInfo is a driver call of tens of microseconds: a round of 512 small shard trees made 2 048 of them, most of
+    // what bench.py's `concurrent_shards` lost between rounds 3 and 4 in a fresh process - small requests are not clamped)
+    if ((uint64_t)want * elem_bytes < (256ull << 20)) return want;
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return want; }
     // (the copying growth holds the old pool until the new one is filled: only the free memory counts)
