@@ -2491,6 +2491,7 @@ struct bbh_tree {
     bool pipe_ml = false;  // the pipelined kernel asked for its multi-level instance (informative levels above the leaf-parents)
     // node-pool compactions (gc_nodes): how many ran, nodes they sealed / left at full capacity (last one), blocks before / after (last one)
     uint64_t gc_runs = 0, gc_sealed = 0, gc_full = 0, gc_before = 0, gc_after = 0;
+    bool lazy_pools = false;  // a fresh tree owns no pools yet: the first call that inserts allocates them at the size it needs (pregrow)
     bool no_seal = false;  // (while the exact batch mode runs: compactions leave every node at full capacity)
     size_t peak_bytes = 0;  // largest sum of this tree's pool allocations (both copies of a pool that is being regrown included)
 };
@@ -2589,6 +2590,10 @@ static int realloc_node_pools(bbh_tree* t, size_t keep, size_t nc, TreeDev* fres
         *fresh_only = n;
         return BBH_OK;
     }
+    // (the memset first: whatever blocking copy follows on the null stream - the carried-over part here, the root header of
+    // a tree without rows in the callers - returns when both are done; a memset left in flight could land on a header a
+    // kernel on another stream has written since)
+    BB_HIP(hipMemset(n.node_hdr + keep, 0, (nc + 1 - keep) * sizeof(NodeHdr)));
     if (keep) {
         const size_t kr = keep * NG;
         BB_HIP(hipMemcpy(n.node_cent, h.node_cent, kr * rb, hipMemcpyDeviceToDevice));
@@ -2597,7 +2602,6 @@ static int realloc_node_pools(bbh_tree* t, size_t keep, size_t nc, TreeDev* fres
         BB_HIP(hipMemcpy(n.node_rm, h.node_rm, kr * sizeof(RowMeta), hipMemcpyDeviceToDevice));
         BB_HIP(hipMemcpy(n.node_hdr, h.node_hdr, keep * sizeof(NodeHdr), hipMemcpyDeviceToDevice));
     }
-    BB_HIP(hipMemset(n.node_hdr + keep, 0, (nc + 1 - keep) * sizeof(NodeHdr)));
     void* old[] = {h.node_cent, h.node_card, h.node_link, h.node_rm, h.node_hdr};
     for (void* q : old)
         if (q) bb::dev_free(q);
@@ -2714,7 +2718,7 @@ int grow_nodes(bbh_tree* t, uint32_t want, uint64_t gc_extra = 0) {  // (gc_extr
     const uint32_t nblk = node_blocks((uint32_t)h.bf + 1);
     // a tree that has not received anything yet owns one empty root: nothing to carry over but its
     // 16-byte header (a multiround round creates hundreds of trees and grows each of them once)
-    const bool pristine = h.cap_nodes > 0 && h.ctr[C_NODES] == nblk && h.ctr[C_IDS] == 0 && h.stats[3] == 0;
+    const bool pristine = h.ctr[C_NODES] == nblk && h.ctr[C_IDS] == 0 && h.stats[3] == 0;
     const uint32_t used = std::min(h.cap_nodes, h.ctr[C_NODES]);
     if (!pristine && h.cap_nodes > 0 && (size_t)used * block_bytes(h) >= gc_min_bytes()) return gc_nodes(t, gc_extra ? gc_extra : (uint64_t)want - used, t->no_seal ? 0 : 1);
     {
@@ -2733,9 +2737,13 @@ int grow_nodes(bbh_tree* t, uint32_t want, uint64_t gc_extra = 0) {  // (gc_extr
 int grow_cf(bbh_tree* t, int tier, uint32_t want) {
     TreeDev& h = t->h;
     const size_t F = (size_t)h.F;
+    // (a tree that has not received anything yet has nothing to carry over: slot 0 of the uint8 pool - SLOT_LAZY8 - is never
+    // looked at.  A multiround round creates hundreds of trees and grows three pools of each of them right away: three
+    // blocking 2 KB copies per tree were a third of bench.py's `concurrent_shards` wall time)
+    const bool pristine = h.ctr[C_IDS] == 0 && h.stats[3] == 0 && h.ctr[C_N16] == 0 && h.ctr[C_N32] == 0 && h.ctr[C_N8] <= 1;
     if (tier == 0 && want > h.cap8) {
         want = fit_to_memory(grow_target(h.cap8, want, F), std::max<uint32_t>(clamp30((uint64_t)h.ctr[C_N8] + 2 * (uint64_t)h.ctr[C_DEPTH] + 64), h.cap8 + 1), h.cap8, F * 1);
-        BB_TRY(grow_pool(h.cf8, (size_t)std::min(h.cap8, h.ctr[C_N8]) * F, (size_t)want * F));
+        BB_TRY(grow_pool(h.cf8, pristine ? 0 : (size_t)std::min(h.cap8, h.ctr[C_N8]) * F, (size_t)want * F));
         h.cap8 = want;
     } else if (tier == 1 && want > h.cap16) {
         want = fit_to_memory(grow_target(h.cap16, want, F * 2), std::max<uint32_t>(clamp30((uint64_t)h.ctr[C_N16] + 2 * (uint64_t)h.ctr[C_DEPTH] + 64), h.cap16 + 1), h.cap16, F * 2);
@@ -2764,15 +2772,16 @@ int init_empty(bbh_tree* t) {
     TreeDev& h = t->h;
     std::memset(h.ctr, 0, sizeof(h.ctr));
     const uint32_t nblk = node_blocks((uint32_t)h.bf + 1);
-    const bool fresh_pools = h.cap_nodes == 0;  // (allocated - and their headers zeroed - right here)
-    BB_TRY(grow_nodes(t, std::max<uint32_t>(h.cap_nodes, (tiny_pools() ? 4 : 64) * nblk)));
-    BB_TRY(grow_cf(t, 0, std::max<uint32_t>(h.cap8, 1024)));
-    BB_TRY(grow_cf(t, 1, std::max<uint32_t>(h.cap16, 64)));
-    BB_TRY(grow_cf(t, 2, std::max<uint32_t>(h.cap32, 256)));
-    NodeHdr root;
-    root.len = 0; root.leaf = hw_make(1u, (uint32_t)h.bf + 1); root.prev = NONE; root.next = NONE;
-    if (!fresh_pools) BB_HIP(hipMemset(h.node_hdr, 0, ((size_t)h.cap_nodes + 1) * sizeof(NodeHdr)));  // (a reset tree: no header of the old one survives)
-    BB_HIP(hipMemcpy(h.node_hdr, &root, sizeof(root), hipMemcpyHostToDevice));
+    // A fresh tree owns no pools: the first call that inserts allocates them once, at the size its elements are expected to
+    // need (pregrow -> grow_nodes writes the root's header).  A multiround round creates hundreds of trees; allocating
+    // minimal pools here and regrowing all of them in the first fit was most of what such a tree cost the host.
+    t->lazy_pools = h.cap_nodes == 0;
+    if (!t->lazy_pools) {  // a reset tree keeps its pools: no header of the old tree survives
+        NodeHdr root;
+        root.len = 0; root.leaf = hw_make(1u, (uint32_t)h.bf + 1); root.prev = NONE; root.next = NONE;
+        BB_HIP(hipMemset(h.node_hdr, 0, ((size_t)h.cap_nodes + 1) * sizeof(NodeHdr)));
+        BB_HIP(hipMemcpy(h.node_hdr, &root, sizeof(root), hipMemcpyHostToDevice));
+    }
     h.ctr[C_NODES] = nblk;
     h.ctr[C_N8] = 1;  // (slot 0 of the uint8 pool is SLOT_LAZY8: never a BitFeature's)
     h.ctr[C_ROOT] = 0;
@@ -2883,6 +2892,13 @@ static bool dense_launch(size_t n_trees, size_t lds_bytes) {
 //   features (uint32): two per node split.
 int pregrow(bbh_tree* t, int64_t n, int width) {
     TreeDev& h = t->h;
+    const bool first = t->lazy_pools;  // the tree's pools come into being here: every pool at least at its minimum
+    t->lazy_pools = false;
+    if (first && tiny_pools()) {
+        BB_TRY(grow_cf(t, 0, 8));
+        BB_TRY(grow_cf(t, 1, 8));
+        BB_TRY(grow_cf(t, 2, 16));
+    }
     if (tiny_pools()) {
         BB_TRY(grow_cf(t, 0, clamp30((uint64_t)h.ctr[C_N8] + 8)));
         BB_TRY(grow_cf(t, 1, clamp30((uint64_t)h.ctr[C_N16] + 8)));
@@ -2891,8 +2907,8 @@ int pregrow(bbh_tree* t, int64_t n, int width) {
         return BBH_OK;
     }
     const uint64_t un = (uint64_t)std::max<int64_t>(n, 0);
-    if (width <= 1) BB_TRY(grow_cf(t, 0, clamp30((uint64_t)h.ctr[C_N8] + un / 8 + 1024)));
-    if (width == 2) BB_TRY(grow_cf(t, 1, clamp30((uint64_t)h.ctr[C_N16] + un + 64)));
+    if (width <= 1 || first) BB_TRY(grow_cf(t, 0, clamp30((uint64_t)h.ctr[C_N8] + (width <= 1 ? un / 8 : 0) + 1024)));
+    if (width == 2 || first) BB_TRY(grow_cf(t, 1, clamp30((uint64_t)h.ctr[C_N16] + (width == 2 ? un : 0) + 64)));
     BB_TRY(grow_nodes(t, clamp30((uint64_t)h.ctr[C_NODES] + (un / (uint64_t)std::max(1, h.bf / 2) + 64) * node_blocks((uint32_t)h.bf + 1))));
     BB_TRY(grow_cf(t, 2, clamp30((uint64_t)h.ctr[C_N32] + un / (uint64_t)std::max(1, h.bf / 6) + 256)));
     return BBH_OK;
@@ -3225,9 +3241,9 @@ int run_insert(bbh_tree* t, const uint8_t* rows_dev, int64_t row_stride, const u
 int build_chain(bbh_tree* t) {
     if (t->chain_valid) return BBH_OK;
     TreeDev& h = t->h;
-    const uint32_t nn = h.ctr[C_NODES];
+    const uint32_t nn = t->lazy_pools ? 0u : h.ctr[C_NODES];  // (a tree that never received anything owns no pools)
     std::vector<NodeHdr> hdr(nn);
-    BB_HIP(hipMemcpy(hdr.data(), h.node_hdr, (size_t)nn * sizeof(NodeHdr), hipMemcpyDeviceToHost));
+    if (nn) BB_HIP(hipMemcpy(hdr.data(), h.node_hdr, (size_t)nn * sizeof(NodeHdr), hipMemcpyDeviceToHost));
     t->chain_nodes.clear();
     t->chain_rows.clear();
     uint32_t nd = h.ctr[C_FIRST_LEAF];
@@ -3712,6 +3728,7 @@ extern "C" int bbh_tree_memory(bbh_tree* t, uint64_t* out8) {
 
 extern "C" int bbh_tree_compact(bbh_tree* t, int32_t seal) {
     if (!t) return bb::fail(BBH_ERR_INVALID, "null tree");
+    if (t->lazy_pools) return BBH_OK;  // (nothing was ever inserted: no pools)
     BB_HIP(hipSetDevice(t->device));
     BB_HIP(hipDeviceSynchronize());
     return gc_nodes(t, 0, seal != 0 ? 1 : 0);

@@ -701,6 +701,58 @@ def single_gpu(args: argparse.Namespace) -> None:
             config3 = {"error": repr(exc)[:200]}
         torch.cuda.empty_cache()
 
+    # A merge round in isolation (reference multiround.py:240-264, :284-312): the round-1 table of a
+    # 1 M-row S-ecfp shard (fit + full refinement at the CLI's bf 254 -> leaf BitFeatures, sorted by size, singletons as a
+    # packed tail) inserted into a fresh tree with the merge rounds' criterion (tolerance-diameter, tol 0.05) - what rounds 2
+    # and 3 of a multiround job do with every table they receive; the C oracle on the first 200 k rows' table beside it
+    merge_round = None
+    if not args.no_extras:
+        try:
+            mr_n = min(n, 1_000_000)
+            mr_fps = synth_ecfp(mr_n, 11, dev)
+
+            def round1_tables(rows, factory=None):
+                kw = {} if factory is None else {"_engine_factory": factory}
+                t = BitBirch(branching_factor=254, threshold=0.3, merge_criterion="diameter", device=local_rank, **kw).fit(rows)
+                t.set_merge("tolerance-diameter", tolerance=0.05, threshold=0.3)
+                t.refine_inplace(rows, n_largest=1)
+                return t._bf_tables(t._leaf_order(True), device=factory is None)
+
+            def insert_tables(bufs, mols, factory=None):
+                kw = {} if factory is None else {"_engine_factory": factory}
+                t = BitBirch(branching_factor=254, threshold=0.3, merge_criterion="tolerance-diameter", tolerance=0.05, device=local_rank, **kw)
+                k_in = 0
+                t0_ = time.perf_counter()
+                for name in bufs:
+                    t._fit_buffers(bufs[name], reinsert_index_seqs=mols[name])
+                    k_in += len(mols[name].counts)
+                if factory is None:
+                    torch.cuda.synchronize()
+                return k_in, time.perf_counter() - t0_, t
+
+            bufs, mols = round1_tables(mr_fps)
+            torch.cuda.synchronize()
+            k_in, dt, mt = insert_tables(bufs, mols)
+            wk = mt._engine.kernel_counts()
+            merge_round = {"rows": mr_n, "bitfeatures_inserted": k_in, "seconds": dt, "elements_per_s": k_in / dt, "us_per_element": 1e6 * dt / k_in,
+                           "elements_by_kernel": {"pipe": int(wk[0]), "fast": int(wk[1]), "complete": int(wk[2])},
+                           "note": "round-1 table of a 1 M-row S-ecfp shard (bf 254, CLI defaults) inserted into a fresh tree with tolerance-diameter"}
+            del bufs, mols, mt
+            if not args.no_cpu:
+                from oracle_engine import OracleEngine
+
+                hs = mr_fps[:200_000].cpu().numpy()
+                ob, om = round1_tables(hs, OracleEngine)
+                k_o, dt_o, ot = insert_tables(ob, om, OracleEngine)
+                merge_round["cpu_baseline"] = {"value": k_o / dt_o, "unit": "elements/s", "cores": 1, "kind": "port", "bitfeatures_inserted": k_o,
+                                               "sample": "the same on the first 200 000 rows through the C oracle, one host core"}
+                merge_round["gpu_over_cpu_core"] = merge_round["elements_per_s"] / (k_o / dt_o)
+                del ob, om, ot
+            del mr_fps
+        except Exception as exc:  # the sub-record must not take the headline down with it
+            merge_round = {"error": repr(exc)[:300]}
+        torch.cuda.empty_cache()
+
     # bf 1000 (what the reference's user guide recommends for 100-200 M molecules, docs/src/user-guide/parameters.rst:95-98):
     # a sample through the GPU engine and through the C oracle on one host core, side by side
     bf1000 = None
@@ -971,6 +1023,7 @@ def single_gpu(args: argparse.Namespace) -> None:
         "bf254": bf254,
         "other_workloads": others,
         "config3": config3,
+        "merge_round": merge_round,
         "bf1000": bf1000,
         "cpu_baseline_bf254": cpu254,
         "distributed_one_rank": dist_one,

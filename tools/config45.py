@@ -111,6 +111,8 @@ def main() -> None:
     print(f"final tree memory: node pools {int(mem[0]) / 1e9:.2f} GB ({int(mem[1]) / 1e9:.2f} GB used = {int(mem[1]) / 1e9 / (n / 1e6):.3f} GB per million "
           f"fingerprints), cluster-feature pools {int(mem[2]) / 1e9:.2f} GB, peak of this tree's allocations {int(mem[3]) / 1e9:.2f} GB; "
           f"{int(mem[4])} compactions, last one: {int(mem[5])} nodes sealed / {int(mem[6])} at full capacity; {int(mem[7])} sealed nodes thawed", flush=True)
+    kc = tree._engine.kernel_counts()
+    print(f"final tree: elements by kernel pipe/fast/complete {kc[:3].tolist()} launches {kc[3:6].tolist()} unsupported-shape stops {int(kc[6])} pool stops {int(kc[7])}", flush=True)
     st = tree._engine.stats()
     print(f"final tree: stats {st.tolist()}", flush=True)
     dist.destroy_process_group()
