@@ -1067,11 +1067,24 @@ __device__ __forceinline__ void majority_rows(const KCt& k, bool lm, uint32_t mr
                 if (lm) c[u] = *(LA uint32_t*)(k.L + k.o.rc_cent + (mrow0 + rc) * k.RBS + (uint32_t)dc * 4);
                 else c[u] = ldg<uint32_t>(cent + (size_t)rc * k.RB + (size_t)dc * 4);
             }
+            // four rows at once through carry-save adders (round 5; a ripple of half adders per row before: 18-27 instructions a
+            // row, three quarters of the 8.9 k cycles this step cost per leaf split at bf 254): c0 + c1 + c2 -> sum, carry;
+            // sum + c3 + plane 0 -> plane 0, carry'; carry + carry' + plane 1 -> plane 1, carry''; carry'' ripples from plane 2
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                uint32_t cc = (actd && r0 + u * TW < m) ? c[u] : 0u;
+            for (int u = 0; u < 4; ++u) c[u] = (actd && r0 + u * TW < m) ? c[u] : 0u;
+            {
+                static_assert(NPW >= 3, "carry-save step needs three planes");
+                const uint32_t x01 = c[0] ^ c[1];
+                const uint32_t s1 = x01 ^ c[2];
+                const uint32_t k1 = (x01 & c[2]) | (~x01 & c[0]);  // majority(c0, c1, c2): one v_bfi_b32
+                const uint32_t x0 = p[0] ^ s1;
+                const uint32_t k2 = (x0 & c[3]) | (~x0 & s1);       // majority(plane 0, sum, c3)
+                p[0] = x0 ^ c[3];
+                const uint32_t x1 = p[1] ^ k1;
+                uint32_t cc = (x1 & k2) | (~x1 & k1);               // majority(plane 1, carry, carry')
+                p[1] = x1 ^ k2;
 #pragma unroll
-                for (int i = 0; i < NPW; ++i) {
+                for (int i = 2; i < NPW; ++i) {
                     const uint32_t t = p[i] & cc;
                     p[i] ^= cc;
                     cc = t;
@@ -1228,8 +1241,13 @@ __device__ __forceinline__ void split_node(const KCt& k, const Elem& el, int& re
             const u64 m1 = __ballot(to1), mv = __ballot(valid);
             const u64 m2 = mv & ~m1;
             if (valid) dst[r] = to1 ? (0x80000000u | (n1 + (uint32_t)__popcll(m1 & below))) : (n2 + (uint32_t)__popcll(m2 & below));
-            nA += wsum64(to1 ? nr : 0ull);
-            nB += wsum64(valid && !to1 ? nr : 0ull);
+            // (n_samples < 2^32: two 16-bit halves summed as 32-bit lanes - 64 x 65 535 fits - instead of 64-bit wave sums)
+            {
+                const uint32_t n32 = (uint32_t)nr, lo16 = n32 & 0xFFFFu, hi16 = n32 >> 16;
+                const bool to2 = valid && !to1;
+                nA += (u64)wsum32(to1 ? lo16 : 0u) + ((u64)wsum32(to1 ? hi16 : 0u) << 16);
+                nB += (u64)wsum32(to2 ? lo16 : 0u) + ((u64)wsum32(to2 ? hi16 : 0u) << 16);
+            }
             n1 += (uint32_t)__popcll(m1);
             n2 += (uint32_t)__popcll(m2);
         }
@@ -1347,10 +1365,25 @@ __device__ __forceinline__ void split_node(const KCt& k, const Elem& el, int& re
             for (uint32_t r0 = 0; r0 < ns; r0 += SPLIT_MLP) {  // this many member CFs in flight
                 uint32_t sw[SPLIT_MLP], rw[SPLIT_MLP], tiers_and = 0xFFFFFFFFu;
                 bool wide = false;
+                // (the group's slot words and rows: one LDS read per lane and v_readlane, not 2 x SPLIT_MLP uniform reads)
+                // (only when whole waves are in this loop - rows of 512 .. 2048 bits: v_readlane reads lanes that must have loaded)
+                static_assert(SPLIT_MLP <= 64, "one entry per lane");
+                const bool whole_waves = (nb & 63) == 0 && nb <= TB;
+                uint32_t swv = 0, rwv = 0;
+                if (whole_waves) {
+                    const uint32_t gl = (uint32_t)tid & 63u, gi = r0 + gl < ns ? r0 + gl : ns - 1;
+                    swv = lst[gi];
+                    rwv = lrow[gi];
+                }
 #pragma unroll
                 for (int u = 0; u < SPLIT_MLP; ++u) {
-                    sw[u] = uni(lst[r0 + u < ns ? r0 + u : ns - 1]);
-                    rw[u] = uni(lrow[r0 + u < ns ? r0 + u : ns - 1]);
+                    if (whole_waves) {
+                        sw[u] = rdlane(swv, u);
+                        rw[u] = rdlane(rwv, u);
+                    } else {
+                        sw[u] = uni(lst[r0 + u < ns ? r0 + u : ns - 1]);
+                        rw[u] = uni(lrow[r0 + u < ns ? r0 + u : ns - 1]);
+                    }
                     wide = wide || (sw[u] >> 30) == 1u || (sw[u] >> 30) == 2u;
                     tiers_and &= sw[u];
                 }
@@ -3490,6 +3523,11 @@ static int insert_u8_buffers(bbh_tree* t, const uint8_t* d, int64_t m, const uin
             if (run1 >= kMinRun) { hi -= run1; break; }
         }
         if (hi == lo) hi = lo + 1;
+        // (every buffer of this run that is appended takes a uint8 slot - pregrow reckoned with an eighth of the call's elements,
+        // which is right for its singleton tail and eight times too little here: the kernel stopped on the exhausted pool, the
+        // host copied all of it into a larger one and relaunched, several times per table)
+        if (!tiny_pools()) rc = grow_cf(t, 0, clamp30((uint64_t)t->h.ctr[C_N8] + (uint64_t)(hi - lo) + 64));
+        if (rc != BBH_OK) break;
         rc = run_insert(t, nullptr, 0, d + (size_t)lo * row_bytes, 1, hi - lo, out ? out + lo : nullptr, s);
         lo = hi;
     }
