@@ -44,6 +44,7 @@ _PROTOTYPES = {
     "bbh_centroid_from_sum": (_int, [_vp, _i32, _i64, _i64, _int, _vp, _vp]),
     "bbh_isim_from_sum": (_int, [_vp, _i32, _i64, _i64, C.POINTER(_f64), C.POINTER(_int), _vp]),
     "bbh_isim_rows": (_int, [_vp, _i64, _i64, _int, _i64, C.POINTER(_f64), C.POINTER(_int), _vp]),
+    "bbh_isim_pair_min_gap": (_int, [_vp, _vp, _i64, _i64, C.POINTER(_f64), _vp]),
     "bbh_most_dissimilar": (
         _int,
         [_vp, _i64, _i64, _i64, C.POINTER(_i64), C.POINTER(_i64), _vp, _vp, _vp],

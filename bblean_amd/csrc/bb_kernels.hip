@@ -812,6 +812,96 @@ extern "C" int bbh_isim_rows(const uint8_t* arr, int64_t n, int64_t n_cols, int 
 }
 
 // =======================================================================================
+// The pair loop of metrics.jt_isim_dunn (bblean/metrics.py:186-199): for every pair of clusters i < j the iSIM of their
+// combined column sums, 1 - iSIM = the pair's gap, the minimum over all pairs.  With a = sums_i, b = sums_j:
+// sum(a + b) = s1_i + s1_j and sum((a + b)^2) = s2_i + s2_j + 2 a.b, so a pair needs ONE exact uint64 dot product (one
+// wave per pair, a cluster's row 64 lanes x F / 64 features) and the reference's float64 formula in its operation order
+// (similarity.cpp:297-300).  Gaps are >= 0: their bit patterns order like the values, the minimum is an atomicMin.
+// =======================================================================================
+__global__ __launch_bounds__(256) void k_isim_pair_min(const unsigned long long* __restrict__ sums, const unsigned long long* __restrict__ sizes,
+                                                       const unsigned long long* __restrict__ s1, const unsigned long long* __restrict__ s2,
+                                                       long long k, long long F, unsigned long long* __restrict__ out_bits) {
+    const long long i = blockIdx.y;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const unsigned long long* a = sums + (size_t)i * (size_t)F;
+    unsigned long long best = 0x3FF0000000000000ull;  // 1.0
+    for (long long j = i + 1 + (long long)blockIdx.x * 4 + wave; j < k; j += (long long)gridDim.x * 4) {
+        const unsigned long long* b = sums + (size_t)j * (size_t)F;
+        unsigned long long dot = 0;
+        for (long long f = lane; f < F; f += 64) dot += a[f] * b[f];
+        dot = wave_sum_u64(dot);
+        const unsigned long long t1 = s1[i] + s1[j], t2 = s2[i] + s2[j] + 2ull * dot, n = sizes[i] + sizes[j];
+        const double gap = 1.0 - isim_from_moments(t1, t2, n);
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(gap < 0.0 ? 0.0 : gap);
+        best = bits < best ? bits : best;
+    }
+    if (lane == 0) atomicMin(out_bits, best);
+}
+
+extern "C" int bbh_isim_pair_min_gap(const uint64_t* sums, const uint64_t* sizes, int64_t k, int64_t n_features, double* out,
+                                     void* stream) {
+    BB_TRY(bb::ensure_device());
+    if (!sums || !sizes || !out || k < 0 || n_features <= 0) return bb::fail(BBH_ERR_INVALID, "null or empty argument");
+    *out = 1.0;
+    if (k < 2) return BBH_OK;
+    hipStream_t s = (hipStream_t)stream;
+    // per-cluster moments on the host (exact uint64, k x F additions): the kernel's work is the k^2 / 2 dot products
+    std::vector<unsigned long long> h1((size_t)k), h2((size_t)k);
+    std::vector<unsigned long long> hs;
+    const unsigned long long* hsums = nullptr;
+    if (bb::is_device_ptr(sums)) {
+        hs.resize((size_t)k * (size_t)n_features);
+        BB_HIP(hipMemcpy(hs.data(), sums, hs.size() * 8, hipMemcpyDeviceToHost));
+        hsums = hs.data();
+    } else {
+        hsums = (const unsigned long long*)sums;
+    }
+    for (int64_t c = 0; c < k; ++c) {
+        unsigned long long a1 = 0, a2 = 0;
+        for (int64_t f = 0; f < n_features; ++f) {
+            const unsigned long long v = hsums[(size_t)c * (size_t)n_features + (size_t)f];
+            a1 += v;
+            a2 += v * v;
+        }
+        h1[(size_t)c] = a1;
+        h2[(size_t)c] = a2;
+    }
+    bb::DevIn dsums, dsizes, d1, d2;
+    BB_TRY(dsums.init(sums, (size_t)k * (size_t)n_features * 8, s));
+    BB_TRY(dsizes.init(sizes, (size_t)k * 8, s));
+    BB_TRY(d1.init(h1.data(), (size_t)k * 8, s));
+    BB_TRY(d2.init(h2.data(), (size_t)k * 8, s));
+    unsigned long long* dout = nullptr;
+    BB_HIP(bb::dev_alloc(&dout, 8));
+    const unsigned long long one = 0x3FF0000000000000ull;
+    int rc = BBH_OK;
+    do {
+        hipError_t e = hipMemcpyAsync(dout, &one, 8, hipMemcpyHostToDevice, s);
+        if (e != hipSuccess) { rc = bb::fail(BBH_ERR_HIP, "H2D: %s", hipGetErrorString(e)); break; }
+        bb::ProfScope ps("isim_pair_min", s);
+        // (grid.y = the pair's first cluster, at most 65 535 per launch; grid.x spreads its partners over workgroups)
+        for (int64_t i0 = 0; i0 + 1 < k && rc == BBH_OK; i0 += 65535) {
+            const unsigned gy = (unsigned)std::min<int64_t>(65535, k - 1 - i0);
+            const unsigned gx = (unsigned)std::min<int64_t>(64, (k + 3) / 4);
+            hipLaunchKernelGGL(k_isim_pair_min, dim3(gx, gy), dim3(256), 0, s, (const unsigned long long*)dsums.dev + (size_t)i0 * (size_t)n_features,
+                               (const unsigned long long*)dsizes.dev + i0, (const unsigned long long*)d1.dev + i0, (const unsigned long long*)d2.dev + i0,
+                               (long long)(k - i0), (long long)n_features, dout);
+            e = hipGetLastError();
+            if (e != hipSuccess) rc = bb::fail(BBH_ERR_HIP, "k_isim_pair_min: %s", hipGetErrorString(e));
+        }
+        if (rc != BBH_OK) break;
+        unsigned long long bits = one;
+        e = hipMemcpyAsync(&bits, dout, 8, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) { rc = bb::fail(BBH_ERR_HIP, "D2H: %s", hipGetErrorString(e)); break; }
+        std::memcpy(out, &bits, 8);
+    } while (false);
+    (void)hipStreamSynchronize(s);
+    bb::dev_free(dout);
+    return rc;
+}
+
+// =======================================================================================
 // jt_most_dissimilar_packed (similarity.cpp:413-471) composed from the kernels above.
 // The tree engine has its own fused in-kernel version (bb_tree.hip, split_node).
 // =======================================================================================

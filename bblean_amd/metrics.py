@@ -16,6 +16,7 @@ import typing as tp
 import numpy as np
 from numpy.typing import NDArray
 
+from bblean_amd import _lib
 from bblean_amd import similarity as _sim
 from bblean_amd.fingerprints import pack_fingerprints
 
@@ -144,10 +145,13 @@ def jt_isim_dunn(
     widest = max(diameters)
     if widest == 0:
         return 1
-    sums = cl.column_sums  # the pair sums of the reference's inner loop are sums of these
-    closest = 1.00
-    for i in range(len(cl) - 1):
-        for j in range(i + 1, len(cl)):
-            gap = 1 - _sim.jt_isim_from_sum(sums[i] + sums[j], cl.sizes[i] + cl.sizes[j])
-            closest = min(gap, closest)
-    return closest / widest
+    # the reference's quadratic pair loop (metrics.py:186-199: iSIM of the two clusters' combined column sums) as ONE call:
+    # a wave per pair, one exact uint64 dot product each (until round 5: a launch and a 16 KB copy per pair)
+    import ctypes as C
+
+    lib = _lib.load()
+    sums = np.ascontiguousarray(np.stack(cl.column_sums).astype(np.uint64, copy=False))
+    sizes = np.ascontiguousarray(np.asarray(cl.sizes, dtype=np.uint64))
+    out = C.c_double(1.0)
+    _lib.check(lib.bbh_isim_pair_min_gap(sums.ctypes.data, sizes.ctypes.data, int(sums.shape[0]), int(sums.shape[1]), C.byref(out), None))
+    return min(out.value, 1.00) / widest

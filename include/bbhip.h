@@ -118,6 +118,12 @@ int bbh_isim_from_sum(const void* linear_sum, int32_t ls_width, int64_t n_featur
 int bbh_isim_rows(const uint8_t* arr, int64_t n, int64_t n_cols, int packed,
                   int64_t n_features, double* out, int* warn, void* stream);
 
+/* The pair loop of metrics.jt_isim_dunn (bblean/metrics.py:186-199) in one call: min over all pairs i < j of
+ * 1 - jt_isim_from_sum(sums[i] + sums[j], sizes[i] + sizes[j]); 1.0 when there are fewer than two clusters.
+ * sums: k x n_features uint64 column sums (host or device), sizes: k uint64; out: host double. */
+int bbh_isim_pair_min_gap(const uint64_t* sums, const uint64_t* sizes, int64_t k, int64_t n_features,
+                          double* out, void* stream);
+
 /* jt_most_dissimilar_packed (similarity.cpp:413-471).  idx1/idx2 are HOST int64;
  * sims1/sims2: n float64 (host or device). */
 int bbh_most_dissimilar(const uint8_t* Y, int64_t n, int64_t nbytes, int64_t n_features,

@@ -34,3 +34,29 @@ def test_metrics_match_reference(c):
     # order: identical up to the last bit; 1e-12 relative is the stated tolerance
     np.testing.assert_allclose(np.array(got, dtype=np.float64), want, rtol=1e-12, atol=0)
     assert np.array_equal(jt_sim_matrix_packed(fps[:37]), GOLD[f"c{c}_simmat"])
+
+
+def test_dunn_pair_kernel_many_clusters():
+    r"""`jt_isim_dunn`'s pair loop (reference metrics.py:186-199) is one launch here (a wave per pair): 90 clusters = 4 005 pairs
+    against the reference's loop restated in NumPy (exact uint64 sums, float64 in the order of similarity.cpp:297-300)."""
+    from bblean_amd.metrics import jt_isim_dunn
+    from bblean_amd.similarity import jt_isim_packed
+
+    rng = np.random.default_rng(5)
+    fps = make_fake_fingerprints(3000, seed=77, pack=True)
+    cuts = np.sort(rng.choice(np.arange(1, 3000), 89, replace=False))
+    clusters = np.split(fps, cuts)
+    got = jt_isim_dunn(clusters)
+    sums = [unpack_fingerprints(c).astype(np.uint64).sum(axis=0) for c in clusters]
+    best = 1.0
+    for i in range(len(clusters) - 1):
+        for j in range(i + 1, len(clusters)):
+            x = sums[i] + sums[j]
+            n = len(clusters[i]) + len(clusters[j])
+            s1, s2 = int(x.sum()), int((x * x).sum())
+            a = np.float64(s2 - s1) / 2.0
+            isim = 1.0 if s1 == 0 else a / ((a + np.float64(n * s1)) - np.float64(s2))
+            best = min(best, 1 - isim)
+    want = best / max(jt_isim_packed(c) for c in clusters)
+    assert got == want
+    assert jt_isim_dunn(clusters[:1]) == 1.0 / jt_isim_packed(clusters[0])
