@@ -485,12 +485,12 @@ def multi_gpu(args: argparse.Namespace, world: int) -> None:
         # sequential on the CPU too and would take ten minutes at 2 M rows per shard)
         msamp = min(n, 100_000)
         with tempfile.TemporaryDirectory() as d:
-            names = []
+            shard_files = []  # (NOT `names`: that is the list of round names the JSON line is keyed by below)
             for r in range(world):
                 f = Path(d) / f"fps.{r:05d}.npy"
                 np.save(f, gen(n, 1000 + r, dev)[:msamp].cpu().numpy())
-                names.append(f)
-            cpu_mr = cpu_multiround_baseline(names, args.bf, args.threshold)
+                shard_files.append(f)
+            cpu_mr = cpu_multiround_baseline(shard_files, args.bf, args.threshold)
     if rank == 0:
         avg_ms = total_ms / max(launches, 1)
         achieved = BYTES_PER_FP * (units / max(launches, 1)) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
