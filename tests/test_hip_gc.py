@@ -77,7 +77,8 @@ def test_gc_between_fit_calls_vs_oracle(bf, kind):
     rows = np.concatenate([_segment(rng, 14_000 * m, kind), _segment(rng, 9_000 * m, kind), _segment(rng, 9_000 * m, (kind + 3) % 6)])
     cuts = [0, 9_000 * m, 9_500 * m, 15_000 * m, 15_000 * m + 1, 22_000 * m, len(rows)]
     kw = dict(branching_factor=bf, threshold=0.35 if kind in (0, 4) else 0.6, merge_criterion="diameter")
-    hip, ora = _fit_both(rows, cuts, kw, compact_between=True)
+    with _Env(BBHIP_GC_MIN_MB="1024"):  # (only the explicit compactions, whatever the process's environment says)
+        hip, ora = _fit_both(rows, cuts, kw, compact_between=True)
     mem = hip._engine.memory()
     assert int(mem[4]) == len(cuts) - 1 and int(mem[5]) > 0 and int(mem[7]) > 0, mem.tolist()
     _same_tables(hip, ora)
@@ -105,7 +106,8 @@ def test_gc_sealed_leaves_give_their_rows_back():
     bits[np.arange(n)[:, None], cols] = True
     rows = np.packbits(bits, axis=1)
     kw = dict(branching_factor=254, threshold=0.3, merge_criterion="diameter")
-    plain = BitBirch(**kw).fit(rows)
+    with _Env(BBHIP_GC_MIN_MB="1024"):
+        plain = BitBirch(**kw).fit(rows)
     used_plain = int(plain._engine.memory()[1])
     with _Env(BBHIP_GC_MIN_MB="0"):
         hip = BitBirch(**kw)
