@@ -2947,6 +2947,14 @@ int pregrow(bbh_tree* t, int64_t n, int width) {
     return BBH_OK;
 }
 
+// longest stretch on the steady-state kernel between two attempts of the pipelined one (see STOP_PIPE_UNSUPPORTED below): 2^16
+// elements.  An attempt that finds the shape still unsupported costs a launch that inserts nothing (~0.2 ms); a stretch that
+// doubled to 2^22 (rounds 3-4) kept S-rdkit-like merge rounds on the slower kernel for millions of elements after the shape
+// had come back (config 5 at 12 M rows: merge round 47.2 -> 44.8 s, profiles/r05/ab_unsup_cap.txt)
+#ifndef BBH_UNSUP_CAP
+#define BBH_UNSUP_CAP (1ll << 16)
+#endif
+
 // One insertion job: a tree and the elements to insert into it.
 struct Job {
     bbh_tree* t;
@@ -3237,12 +3245,12 @@ int run_insert_multi(std::vector<Job>& jobs, hipStream_t s) {
                 case STOP_RANGE: rc = bb::fail(BBH_ERR_INVALID, "n_samples exceeds 2^32-1 (engine limit)"); break;
                 case STOP_PIPE_UNSUPPORTED:
                     // a stretch on the steady-state kernel, then the pipeline again.  A tree that keeps its unsupported shape
-                    // would pay a launch that inserts nothing after every stretch: the stretch doubles (up to 4 M elements)
+                    // would pay a launch that inserts nothing after every stretch: the stretch doubles (up to BBH_UNSUP_CAP = 65 536 elements)
                     // while the pipeline makes no progress and starts again at 1 024 as soon as it does
                     // (a tree that has been in the pipeline: informative levels above the leaf-parents are mostly short-lived
                     // there - a freshly split node's tracking row - so the first stretch is short; a new tree needs its first
                     // 8 192 elements to get the shape at all)
-                    t->unsup_stretch = t->unsup_stretch == 0 ? 8192 : (back.processed > 0 ? 1024 : std::min<int64_t>(t->unsup_stretch * 2, 1ll << 22));
+                    t->unsup_stretch = t->unsup_stretch == 0 ? 8192 : (back.processed > 0 ? 1024 : std::min<int64_t>(t->unsup_stretch * 2, BBH_UNSUP_CAP));
                     j.old_left = t->unsup_stretch;
                     break;
                 case STOP_PIPE_NEEDS_ML: t->pipe_ml = true; break;  // relaunched at once, with the multi-level instance
