@@ -174,6 +174,12 @@ __device__ __forceinline__ uint32_t row_ror(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x120 + N, 0xF, 0xF, false);
 }
 
+// any other DPP control word inside a 16-lane row (0x141 row_half_mirror, 0x00-0xFF quad_perm), folded into an add the same way
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_ctrl(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, false);
+}
+
 // Sum over the 16 lanes of a DPP row; result in every lane of the row.
 __device__ __forceinline__ uint32_t row16_sum(uint32_t v) {
     v += row_ror<8>(v);

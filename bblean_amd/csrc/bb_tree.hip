@@ -631,18 +631,28 @@ __device__ __forceinline__ Cand node_best(const KCt& k, int& cmp_par, uint32_t n
                 // in registers until their block is consumed.
                 constexpr int NP = 16;
                 constexpr uint32_t BLK = NP * 16;
+                // The 16 partial counts of a row sit in the 16 lanes of its group, and a block hands every group 16 rows: the
+                // 16 x 16 partials are summed by a TRANSPOSING butterfly (lane l of the group ends with the sum for pass l:
+                // 15 select-select-add steps instead of 16 x 4 DPP adds), and everything behind the sum - union, counts for
+                // the split, the running first-argmax - runs once per block on 16 different rows per group instead of
+                // sixteen times on one (592 -> ~280 vector instructions per block and wave; a 1001-row compare was bound
+                // by exactly these).  The row a lane looks after within a block is rs + l * 16 + g.
                 u32x4_t dA[NP], dB[NP];
-                uint32_t lkA[NP], lkB[NP];
-                auto issue = [&](u32x4_t (&d)[NP], uint32_t (&lk)[NP], uint32_t rs) {
+                uint32_t lkA = 0, lkB = 0;
+                auto issue = [&](u32x4_t (&d)[NP], uint32_t& lk, uint32_t rs) {
 #pragma unroll
                     for (int p = 0; p < NP; ++p) {
                         const uint32_t r = rs + p * 16 + g;
                         const uint32_t rc = r < last ? r : last;
                         d[p] = ldg<u32x4_t>(k.cent + (meta + rc) * 256 + l * 16);
-                        lk[p] = want_link ? ldg<uint32_t>(k.link + meta + rc) : 0u;
+                    }
+                    if (want_link) {
+                        const uint32_t r = rs + l * 16 + g;
+                        lk = ldg<uint32_t>(k.link + meta + (r < last ? r : last));
                     }
                 };
-                auto consume = [&](const u32x4_t (&d)[NP], const uint32_t (&lk)[NP], uint32_t rs) {
+                const bool b3 = (l & 8) != 0, b2 = (l & 4) != 0, b1 = (l & 2) != 0, b0 = (l & 1) != 0;
+                auto consume = [&](const u32x4_t (&d)[NP], uint32_t lk, uint32_t rs) {
                     if (rs == 0) {
                         if (load_hdr) {
                             len = uni(hraw.x);
@@ -651,21 +661,30 @@ __device__ __forceinline__ Cand node_best(const KCt& k, int& cmp_par, uint32_t n
                             len = (uint32_t)known_len;
                         }
                     }
+                    // (a row's popcount is counted from the row itself, in the high half)
+                    uint32_t v8[8], v4[4], v2[2];
 #pragma unroll
-                    for (int p = 0; p < NP; ++p) {
-                        const uint32_t r = rs + p * 16 + g;
-                        if (want_link && l == 0 && r < rows) s_link[r] = lk[p];
-                        const uint32_t both = row16_sum(popc4v(d[p] & xv) + (popc4v(d[p]) << 16));
-                        const uint32_t inter = both & 0xFFFFu;
-                        uint32_t un = (both >> 16) + vec_pc - inter;
-                        anyc = anyc || (r < len && (both >> 16) != 0);
-                        if (want_counts && r < len && l == 0) { s_i[r] = inter; s_u[r] = un; }
-                        un = un < 1u ? 1u : un;
-                        const bool take = r < len && cand_better<MINMODE>(inter, un, r, bi, bu, br);
-                        bi = take ? inter : bi;
-                        bu = take ? un : bu;
-                        br = take ? r : br;
+                    for (int j = 0; j < 8; ++j) {
+                        const uint32_t lo = popc4v(d[j] & xv) + (popc4v(d[j]) << 16);
+                        const uint32_t hi = popc4v(d[j + 8] & xv) + (popc4v(d[j + 8]) << 16);
+                        v8[j] = (b3 ? hi : lo) + row_ror<8>(b3 ? lo : hi);  // partner l ^ 8
                     }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v4[j] = (b2 ? v8[j + 4] : v8[j]) + dpp_ctrl<0x141>(b2 ? v8[j] : v8[j + 4]);  // row_half_mirror: partner (l & 8) | (7 - (l & 7))
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) v2[j] = (b1 ? v4[j + 2] : v4[j]) + dpp_ctrl<0x4E>(b1 ? v4[j] : v4[j + 2]);  // quad_perm [2,3,0,1]: partner l ^ 2
+                    const uint32_t both = (b0 ? v2[1] : v2[0]) + dpp_ctrl<0xB1>(b0 ? v2[0] : v2[1]);  // quad_perm [1,0,3,2]: partner l ^ 1
+                    const uint32_t r = rs + (uint32_t)l * 16 + g;
+                    if (want_link && r < rows) s_link[r] = lk;
+                    const uint32_t inter = both & 0xFFFFu;
+                    uint32_t un = (both >> 16) + vec_pc - inter;
+                    anyc = anyc || (r < len && (both >> 16) != 0);
+                    if (want_counts && r < len) { s_i[r] = inter; s_u[r] = un; }
+                    un = un < 1u ? 1u : un;
+                    const bool take = r < len && cand_better<MINMODE>(inter, un, r, bi, bu, br);
+                    bi = take ? inter : bi;
+                    bu = take ? un : bu;
+                    br = take ? r : br;
                 };
                 // (only the node's `len` rows are walked, not all bf + 1: the length arrives with the first block - until round 4
                 // a half-full node of a bf 1000 tree cost what a full one does)
@@ -678,6 +697,18 @@ __device__ __forceinline__ Cand node_best(const KCt& k, int& cmp_par, uint32_t n
                     issue(dA, lkA, r_start + 2 * BLK);
                     if (r_start + BLK < lim) consume(dB, lkB, r_start + BLK);
                 }
+                // the lanes of a group hold different rows' candidates here: rotate-and-keep-better leaves the group's first
+                // best in all 16 of them, as the code below expects
+#define BB_GSTEP(N)                                                                          \
+    {                                                                                        \
+        const uint32_t oi = row_ror<N>(bi), ou = row_ror<N>(bu), orr = row_ror<N>(br);       \
+        const bool tk = cand_better<MINMODE>(oi, ou, orr, bi, bu, br);                       \
+        bi = tk ? oi : bi;                                                                   \
+        bu = tk ? ou : bu;                                                                   \
+        br = tk ? orr : br;                                                                  \
+    }
+                BB_GSTEP(8) BB_GSTEP(4) BB_GSTEP(2) BB_GSTEP(1)
+#undef BB_GSTEP
                 r_start = rows;  // (every row below `len` has been looked at)
             }
         }
