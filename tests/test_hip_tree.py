@@ -255,6 +255,29 @@ def test_hip_pipelined_kernel_drifting_centroids_vs_oracle(bf):
     assert int(st[2]) > 5000  # (the noisy copies do merge)
 
 
+@pytest.mark.parametrize("bf,crit", [(256, "diameter"), (300, "diameter"), (520, "radius"), (770, "tolerance-diameter")])
+def test_hip_tree_block_compare_boundaries_vs_oracle(bf, crit):
+    r"""Branching factors above 255 compare a node in blocks of 256 rows that are requested only when the node reaches them
+    (node_best's block path, bb_tree.hip): nodes of 257 rows (one block and one row), leaves whose length crosses 256 / 512 /
+    768 as they fill and split, a root of a few rows (the 64-row pass) that grows past 64 and past 256 (bf 256 at 150 k rows),
+    the first-argmin of the splits through the same path.  Per-element leaf ids, counters and centroids equal the oracle's."""
+    import torch
+
+    from bench import synth_fake_fps
+
+    n = 150_000
+    fps = synth_fake_fps(n, seed=3000 + bf, device=torch.device("cuda"))
+    kw = dict(branching_factor=bf, threshold=0.3, merge_criterion=crit)
+    if crit.startswith("tolerance"):
+        kw["tolerance"] = 0.05
+    hip = BitBirch(**kw).fit(fps)
+    ora = BitBirch(**kw, _engine_factory=OracleEngine).fit(fps.cpu().numpy())
+    assert (hip.get_assignments() == ora.get_assignments()).all()
+    assert hip._engine.stats()[:7].tolist() == ora._engine.stats()[:7].tolist()
+    lv_h, lv_o = hip._leaves(), ora._leaves()
+    assert (lv_h["cents"] == lv_o["cents"]).all() and (lv_h["n"] == lv_o["n"]).all()
+
+
 @pytest.mark.parametrize("bf", [254, 1000])
 def test_hip_tree_1M_large_branching_factors_vs_oracle(bf):
     r"""The CLI default (bf 254) and the branching factor the reference recommends for 100-200 M molecules (bf 1000,
