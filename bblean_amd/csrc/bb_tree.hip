@@ -620,38 +620,45 @@ __device__ __forceinline__ Cand node_best(const KCt& k, int& cmp_par, uint32_t n
         uint32_t r_start = 0;
         if constexpr (!ROOT) {
             // Nodes far larger than the block's 16 rows per pass (branching factors of several hundred: nothing of them is
-            // mirrored in LDS, every level streams from L2): 16 passes = 256 rows requested before the first is consumed,
-            // instead of one memory round trip per 64 rows.
+            // mirrored in LDS, every level streams from L2): two blocks of 8 passes = 256 rows requested before the first is
+            // consumed, instead of one memory round trip per 64 rows.
             if (!fill && rows > 256) {
-                // Blocks of 256 rows (16 passes of the block's 16 rows), double-buffered: the next block's rows are on their
+                // Blocks of 128 rows (8 passes of the block's 16 rows), double-buffered: the next block's rows are on their
                 // way while this one's are counted - with one block at a time a 1001-row node was four exposed memory round
-                // trips (41 k cycles per level at bf 1000).  Requests are unconditional (rows beyond the node are clamped to
-                // its last row): a conditional request makes the compiler wait for everything outstanding at the join.  A
-                // row's popcount is counted from the row itself (same reduction, high half) instead of loaded, links wait
-                // in registers until their block is consumed.
-                constexpr int NP = 16;
+                // trips (41 k cycles per level at bf 1000).  Requests carry no branch (a conditional request makes the
+                // compiler wait for everything outstanding at the join): they are BUFFER loads bounded by the node's live bytes
+                // as soon as the length is known - lanes beyond the end are out of range, return zero and ask the memory system
+                // for nothing (tools/probe/ta_request_cost.cpp) - and blocks are 128 rows, not 256, because what is requested
+                // blind (block B, before the header has arrived) and ahead of the end queues in front of the next dependent
+                // load: timed inside this function, a level of S-fake's bf 1000 tree spent 2.2 k cycles issuing two 256-row
+                // blocks for nodes of 124-314 live rows (profiles/r05/bf1000_node_best_timeline.txt).  A row's popcount is
+                // counted from the row itself (same reduction, high half) instead of loaded, links wait in registers until
+                // their block is consumed.
+                constexpr int NP = 8;
                 constexpr uint32_t BLK = NP * 16;
-                // The 16 partial counts of a row sit in the 16 lanes of its group, and a block hands every group 16 rows: the
-                // 16 x 16 partials are summed by a TRANSPOSING butterfly (lane l of the group ends with the sum for pass l:
-                // 15 select-select-add steps instead of 16 x 4 DPP adds), and everything behind the sum - union, counts for
-                // the split, the running first-argmax - runs once per block on 16 different rows per group instead of
-                // sixteen times on one (592 -> ~280 vector instructions per block and wave; a 1001-row compare was bound
-                // by exactly these).  The row a lane looks after within a block is rs + l * 16 + g.
+                uint32_t nrec = rows * 256u;  // bytes of the node's rows that exist, as far as known: the bound of the buffer loads
+                // The 16 partial counts of a row sit in the 16 lanes of its group, and a block hands every group 8 rows: the
+                // 16 x 8 partials are summed by a TRANSPOSING butterfly inside each half-row of 8 lanes (select, select,
+                // v_add_u32_dpp with row_half_mirror, quad_perm [2,3,0,1], [1,0,3,2]: 7 steps, lane l ends with its half-row's
+                // sum for pass l & 7) and one row_ror:8 add brings the two half-rows together, instead of 8 x 4 DPP adds; and
+                // everything behind the sum - union, counts for the split, the running first-argmax - runs once per block on 8
+                // different rows per group (lanes l and l ^ 8 the same one) instead of eight times on one.  The row a lane looks
+                // after within a block is rs + (l & 7) * 16 + g.
                 u32x4_t dA[NP], dB[NP];
                 uint32_t lkA = 0, lkB = 0;
                 auto issue = [&](u32x4_t (&d)[NP], uint32_t& lk, uint32_t rs) {
+                    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(k.cent + meta * 256), 0, (int)nrec, 0x00020000);
 #pragma unroll
                     for (int p = 0; p < NP; ++p) {
                         const uint32_t r = rs + p * 16 + g;
-                        const uint32_t rc = r < last ? r : last;
-                        d[p] = ldg<u32x4_t>(k.cent + (meta + rc) * 256 + l * 16);
+                        d[p] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(r * 256 + l * 16), 0, 0));
                     }
                     if (want_link) {
-                        const uint32_t r = rs + l * 16 + g;
+                        const uint32_t r = rs + (l & 7) * 16 + g;
                         lk = ldg<uint32_t>(k.link + meta + (r < last ? r : last));
                     }
                 };
-                const bool b3 = (l & 8) != 0, b2 = (l & 4) != 0, b1 = (l & 2) != 0, b0 = (l & 1) != 0;
+                const bool b2 = (l & 4) != 0, b1 = (l & 2) != 0, b0 = (l & 1) != 0;
                 auto consume = [&](const u32x4_t (&d)[NP], uint32_t lk, uint32_t rs) {
                     if (rs == 0) {
                         if (load_hdr) {
@@ -662,19 +669,18 @@ __device__ __forceinline__ Cand node_best(const KCt& k, int& cmp_par, uint32_t n
                         }
                     }
                     // (a row's popcount is counted from the row itself, in the high half)
-                    uint32_t v8[8], v4[4], v2[2];
+                    uint32_t v4[4], v2[2];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
+                    for (int j = 0; j < 4; ++j) {
                         const uint32_t lo = popc4v(d[j] & xv) + (popc4v(d[j]) << 16);
-                        const uint32_t hi = popc4v(d[j + 8] & xv) + (popc4v(d[j + 8]) << 16);
-                        v8[j] = (b3 ? hi : lo) + row_ror<8>(b3 ? lo : hi);  // partner l ^ 8
+                        const uint32_t hi = popc4v(d[j + 4] & xv) + (popc4v(d[j + 4]) << 16);
+                        v4[j] = (b2 ? hi : lo) + dpp_ctrl<0x141>(b2 ? lo : hi);
                     }
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) v4[j] = (b2 ? v8[j + 4] : v8[j]) + dpp_ctrl<0x141>(b2 ? v8[j] : v8[j + 4]);  // row_half_mirror: partner (l & 8) | (7 - (l & 7))
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) v2[j] = (b1 ? v4[j + 2] : v4[j]) + dpp_ctrl<0x4E>(b1 ? v4[j] : v4[j + 2]);  // quad_perm [2,3,0,1]: partner l ^ 2
-                    const uint32_t both = (b0 ? v2[1] : v2[0]) + dpp_ctrl<0xB1>(b0 ? v2[0] : v2[1]);  // quad_perm [1,0,3,2]: partner l ^ 1
-                    const uint32_t r = rs + (uint32_t)l * 16 + g;
+                    for (int j = 0; j < 2; ++j) v2[j] = (b1 ? v4[j + 2] : v4[j]) + dpp_ctrl<0x4E>(b1 ? v4[j] : v4[j + 2]);
+                    uint32_t both = (b0 ? v2[1] : v2[0]) + dpp_ctrl<0xB1>(b0 ? v2[0] : v2[1]);
+                    both += row_ror<8>(both);  // the other half-row's eight lanes: the same pass (l & 7)
+                    const uint32_t r = rs + (uint32_t)(l & 7) * 16 + g;
                     if (want_link && r < rows) s_link[r] = lk;
                     const uint32_t inter = both & 0xFFFFu;
                     uint32_t un = (both >> 16) + vec_pc - inter;
@@ -693,7 +699,7 @@ __device__ __forceinline__ Cand node_best(const KCt& k, int& cmp_par, uint32_t n
                 for (; r_start < lim; r_start += 2 * BLK) {
                     issue(dB, lkB, r_start + BLK);
                     consume(dA, lkA, r_start);
-                    if (r_start == 0) lim = len < rows ? len : rows;
+                    if (r_start == 0) { lim = len < rows ? len : rows; nrec = lim * 256u; }
                     issue(dA, lkA, r_start + 2 * BLK);
                     if (r_start + BLK < lim) consume(dB, lkB, r_start + BLK);
                 }
