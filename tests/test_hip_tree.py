@@ -257,10 +257,10 @@ def test_hip_pipelined_kernel_drifting_centroids_vs_oracle(bf):
 
 @pytest.mark.parametrize("bf,crit", [(256, "diameter"), (300, "diameter"), (520, "radius"), (770, "tolerance-diameter")])
 def test_hip_tree_block_compare_boundaries_vs_oracle(bf, crit):
-    r"""Branching factors above 255 compare a node in blocks of 256 rows that are requested only when the node reaches them
-    (node_best's block path, bb_tree.hip): nodes of 257 rows (one block and one row), leaves whose length crosses 256 / 512 /
-    768 as they fill and split, a root of a few rows (the 64-row pass) that grows past 64 and past 256 (bf 256 at 150 k rows),
-    the first-argmin of the splits through the same path.  Per-element leaf ids, counters and centroids equal the oracle's."""
+    r"""Branching factors above 255 compare a node in double-buffered blocks of 128 rows, requested through buffer loads bounded
+    by the node's live bytes (node_best's block path, bb_tree.hip): node slots of 257 rows (two blocks and one row), leaves whose
+    length crosses the block boundaries (128, 256, ... 768) as they fill and split, roots from a few rows up to bf, the
+    first-argmin of the splits through the same path.  Per-element leaf ids, counters and centroids equal the oracle's."""
     import torch
 
     from bench import synth_fake_fps
