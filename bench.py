@@ -35,7 +35,7 @@ REPO = Path(__file__).resolve().parent
 sys.path.insert(0, str(REPO))
 sys.path.insert(0, str(REPO / "tests"))
 
-PREVIOUS_ROUND = "r04"  # profiles/<round>/bench_line_final.json: what `regressions` compares this line with
+PREVIOUS_ROUND = "r05"  # BENCH_<round>.json (the driver's line) + profiles/<round>/bench_line_final.json: what `regressions` compares this line with
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 BYTES_PER_FP = 264  # 256 B row read once + 8 B label
 _W8 = [128, 64, 32, 16, 8, 4, 2, 1]
@@ -302,30 +302,93 @@ def cpu_multiround_baseline(files: list[Path], bf: int, thr: float, bin_size: in
                       "the final merge in one"}
 
 
-def regressions(out: dict, prev_file: Path, tolerance: float = 0.05) -> dict:
-    r"""Every throughput of this line next to the same entry of the previous round's committed line: entries more than
-    `tolerance` worse are listed (two regressions went unnoticed for a round).  GPU rates only - the CPU
-    baselines move with the box."""
-    names = {"fingerprints_per_s", "gpu_fingerprints_per_s", "achieved", "value"}
-    try:
-        prev = json.loads(prev_file.read_text())
-    except Exception as exc:
-        return {"against": str(prev_file), "error": repr(exc)[:120]}
+def regressions(out: dict, prev_files: list, tolerance: float = 0.05) -> dict:
+    r"""Every GPU throughput of this line next to the same entry of the previous round: the DRIVER's line
+    (`BENCH_rNN.json:parsed`, measured by the judge's harness) where it has the entry, the builder's committed full line
+    (`profiles/rNN/bench_line_final.json`) for the sub-records the driver's file does not keep.  Entries more than
+    `tolerance` worse are listed - and when the entry carries its repeats (`<name>_repeats`), only if at least two of three
+    are worse (a guard that fires on box noise every round is ignored the round it is right).  The
+    file-based multiround is compared on its summed kernel time (`kernel_fingerprints_per_s`), not on wall time with the
+    box's file system inside.  CPU baselines are not compared: they move with the host."""
+    names = {"fingerprints_per_s", "gpu_fingerprints_per_s", "kernel_fingerprints_per_s", "achieved", "value", "elements_per_s"}
+    prev: dict = {}
+    used = []
+
+    def merge(dst, src):
+        for k, v in src.items():
+            if isinstance(v, dict) and isinstance(dst.get(k), dict):
+                merge(dst[k], v)
+            else:
+                dst[k] = v
+
+    for f in prev_files:  # (later files override earlier ones)
+        try:
+            rec = json.loads(Path(f).read_text())
+            rec = rec.get("parsed", rec) if isinstance(rec, dict) else {}
+            if isinstance(rec, dict) and rec:
+                merge(prev, rec)
+                used.append(str(Path(f).relative_to(REPO)) if Path(f).is_relative_to(REPO) else str(f))
+        except Exception:
+            continue
+    if not prev:
+        return {"against": [str(f) for f in prev_files], "error": "no previous line readable"}
 
     def walk(a, b, path, acc):
         if isinstance(a, dict) and isinstance(b, dict):
             for k in a:
-                if k in b and "cpu" not in k and k not in ("projected_8gpu", "traffic_source"):
+                if k in b and "cpu" not in k and k not in ("projected_8gpu", "traffic_source", "plan", "regressions"):
                     walk(a[k], b[k], path + [k], acc)
+                    if k in names and isinstance(a.get(k + "_repeats"), list):
+                        acc[-1] = acc[-1] + (a[k + "_repeats"],)
         elif path and path[-1] in names and isinstance(a, (int, float)) and isinstance(b, (int, float)) and b > 0:
             acc.append((".".join(path), float(a), float(b)))
 
     pairs: list = []
     walk(out, prev, [], pairs)
-    worse = {k: {"now": a, "before": b, "ratio": round(a / b, 3)} for k, a, b in pairs if a < (1.0 - tolerance) * b}
-    better = {k: round(a / b, 3) for k, a, b in pairs if a > (1.0 + tolerance) * b}
-    return {"against": str(prev_file.relative_to(REPO)) if prev_file.is_relative_to(REPO) else str(prev_file), "compared": len(pairs),
-            "tolerance": tolerance, "worse": worse, "better": better}
+    worse, better = {}, {}
+    for item in pairs:
+        k, a, b = item[:3]
+        reps = item[3] if len(item) > 3 else None
+        if a < (1.0 - tolerance) * b:
+            if reps is not None and sum(1 for r in reps if r < (1.0 - tolerance) * b) < 2:
+                continue
+            worse[k] = {"now": a, "before": b, "ratio": round(a / b, 3), "repeats": reps}
+        elif a > (1.0 + tolerance) * b:
+            better[k] = round(a / b, 3)
+    return {"against": used, "compared": len(pairs), "tolerance": tolerance, "worse": worse, "better": better}
+
+
+# --- sizing of the N > 1 job (VERDICT r5 item 3) --------------------------------------------------------------
+# One step of the multiround job costs, per row of a shard: round 1 (fit + full refinement on the shard's own GPU) and,
+# for EVERY shard of the job, two sequential passes on the merging rank (merge round + final merge: the reference's
+# Amdahl shape, multiround.py:443-470).  Rates measured on one MI355X at bf 254 on S-ecfp rows
+# (profiles/r05/bench_line_distributed_one_rank.json: 11.6 / 6.8 / 6.0 s for one shard of 2 M rows).
+PLAN_ROUND1_S_PER_ROW = 5.8e-6
+PLAN_MERGE_S_PER_ROW = 6.4e-6
+PLAN_BUDGET_S = 1200.0      # (warmup + steps) x step must fit this (the driver allows 1 800 s per run)
+PLAN_REF_WORLD = 8          # the shard is sized for the largest job the driver runs, so that every N times EQUAL work per GPU
+PLAN_MAX_ROWS = 2_000_000
+PLAN_STATED_ROWS = 12_500_000  # BASELINE configs[3]: 100 M rows in 8 shards
+
+
+def plan_step_seconds(world: int, rows: int, scale: float = 1.0) -> float:
+    return scale * rows * (PLAN_ROUND1_S_PER_ROW + world * PLAN_MERGE_S_PER_ROW)
+
+
+def plan_rows_per_shard(steps: int, warmup: int, world: int = PLAN_REF_WORLD, scale: float = 1.0, cap: int = PLAN_MAX_ROWS) -> int:
+    r"""Rows per shard such that (warmup + steps) steps of the `world`-rank job fit PLAN_BUDGET_S, in multiples of 50 000."""
+    per_row = scale * (PLAN_ROUND1_S_PER_ROW + world * PLAN_MERGE_S_PER_ROW) * max(steps + warmup, 1)
+    rows = int(PLAN_BUDGET_S / per_row)
+    return max(50_000, min(cap, rows // 50_000 * 50_000))
+
+
+def plan_multi(world: int, steps: int, warmup: int, n_fps: int | None = None) -> dict:
+    rows = n_fps if n_fps is not None else plan_rows_per_shard(steps, warmup, max(world, PLAN_REF_WORLD))
+    step = plan_step_seconds(world, rows)
+    return {"world": world, "steps": steps, "warmup": warmup, "rows_per_shard": rows, "rows_per_shard_stated": PLAN_STATED_ROWS,
+            "sized_for_world": max(world, PLAN_REF_WORLD), "overridden_by_n_fps": n_fps is not None,
+            "projected_step_s": round(step, 2), "projected_wall_s": round((steps + warmup) * step, 1), "budget_s": PLAN_BUDGET_S,
+            "model": {"round1_s_per_row": PLAN_ROUND1_S_PER_ROW, "merge_s_per_row_and_shard": PLAN_MERGE_S_PER_ROW}}
 
 
 def _free_port() -> int:
@@ -353,7 +416,8 @@ def parse() -> argparse.Namespace:
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--n-fps", type=int, default=None,
-                    help="rows per GPU (default 1 000 000 at N=1, 2 000 000 per GPU at N>1; BASELINE configs[3] states 12 500 000)")
+                    help="rows per GPU (default 1 000 000 at N=1; at N>1 sized so that (warmup + steps) steps of the 8-GPU job fit "
+                         "20 minutes, at most 2 000 000 - `--dry-run` prints the plan; BASELINE configs[3] states 12 500 000)")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default=None,
                     help="default: fake at N=1 (BASELINE configs[1]), ecfp at N>1 (configs[3])")
     ap.add_argument("--bf", type=int, default=None, help="default: 50 at N=1 (configs[1]), 254 at N>1 (the CLI default, configs[3])")
@@ -365,6 +429,7 @@ def parse() -> argparse.Namespace:
     ap.add_argument("--multiround-files", type=int, default=64, help="0 skips the file-based multiround run")
     ap.add_argument("--no-extras", action="store_true", help="skip the sub-records (bf 254, other workloads, config 3, bf 1000, one-rank distributed)")
     ap.add_argument("--config3-rows", type=int, default=10_000_000, help="rows of the config-3 sub-record (0 skips it)")
+    ap.add_argument("--dry-run", action="store_true", help="print the plan of the N > 1 job (rows per shard, projected wall time) and exit")
     ap.add_argument("--distributed", action="store_true",
                     help="time the one-rank-per-GPU multiround path even at N=1 (what N>1 always times)")
     return ap.parse_args()
@@ -379,6 +444,9 @@ def _emit(out: dict) -> None:
 
 def main() -> None:
     args = parse()
+    if args.dry_run:
+        print(json.dumps(plan_multi(args.gpus, args.steps, args.warmup, args.n_fps)))
+        return
     env_world = os.environ.get("WORLD_SIZE")
     if env_world is None and (args.gpus > 1 or args.distributed):
         # `python bench.py --gpus N` run bare: N ranks of this same script, one per GPU
@@ -404,8 +472,9 @@ def main() -> None:
         args.bf = 254 if multi else 50
     if args.threshold is None:
         args.threshold = WORKLOADS[args.workload][1]
+    args.n_fps_given = args.n_fps is not None
     if args.n_fps is None:
-        args.n_fps = 2_000_000 if multi else 1_000_000
+        args.n_fps = plan_multi(world, args.steps, args.warmup)["rows_per_shard"] if multi else 1_000_000
     if world == 1 and not args.distributed:
         single_gpu(args)
     else:
@@ -430,14 +499,15 @@ def multi_gpu(args: argparse.Namespace, world: int) -> None:
     lib = _lib.load()
     n = args.n_fps
     gen = WORKLOADS[args.workload][0]
+    plan = plan_multi(world, args.steps, args.warmup, n if args.n_fps_given else None)
     shard = gen(n, 1000 + rank, dev)  # this rank's shard, resident in HBM
     torch.cuda.synchronize()
-    inputs = [ShardRows(n) for _ in range(world)]
-    inputs[rank] = shard
 
     state: dict = {}
 
-    def one_step() -> None:
+    def one_step(rows: int) -> None:
+        inputs = [ShardRows(rows) for _ in range(world)]
+        inputs[rank] = shard[:rows]
         tree, timer = run_multiround_distributed(inputs, None, branching_factor=args.bf, threshold=args.threshold,
                                                  device=local_rank, return_tree=True)
         if tree is not None:  # rank 0: the labels are part of "clustered"
@@ -449,14 +519,38 @@ def multi_gpu(args: argparse.Namespace, world: int) -> None:
         dist.barrier()
         torch.cuda.synchronize()
 
+    def timed(rows: int) -> float:
+        barrier()
+        t_ = time.perf_counter()
+        one_step(rows)
+        barrier()
+        tt_ = torch.tensor([time.perf_counter() - t_], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt_, op=dist.ReduceOp.MAX)
+        return float(tt_.item())
+
+    # A measured step on the first rows of every shard (the same rows the CPU baseline below is timed on): it calibrates the
+    # plan - if (warmup + steps) steps at the planned size would not fit the budget on THIS box, the shard shrinks (every rank
+    # computes the same number from the all-reduced time) - and it is the GPU figure on the CPU baseline's sample.
+    n_cal = min(n, 100_000)
+    timed(n_cal)  # (first call: library load, RCCL communicator, pools)
+    t_cal = timed(n_cal)
+    scale = t_cal / plan_step_seconds(world, n_cal)
+    plan["calibration"] = {"rows_per_shard": n_cal, "step_s": round(t_cal, 3), "fingerprints_per_s": world * n_cal / t_cal,
+                           "measured_over_model": round(scale, 3)}
+    # (small shards are dearer per row than the model's large ones: the projection from them is an upper bound)
+    projected = (args.warmup + args.steps) * plan_step_seconds(world, n, min(scale, 3.0))
+    if projected > 1.25 * PLAN_BUDGET_S and not args.n_fps_given:
+        n = max(50_000, int(n * PLAN_BUDGET_S / projected) // 50_000 * 50_000)
+        plan["shrunk_to"] = n
+    plan["rows_per_shard_run"] = n
     for _ in range(args.warmup):
-        one_step()
+        one_step(n)
     lib.bbh_profile_enable(1)
     lib.bbh_profile_reset()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        one_step()
+        one_step(n)
     barrier()
     elapsed = time.perf_counter() - t0
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -483,7 +577,7 @@ def multi_gpu(args: argparse.Namespace, world: int) -> None:
 
         # (a bounded sample: the first 100 000 rows of every rank's shard - 10-30 s of host work; the whole job's merge rounds are
         # sequential on the CPU too and would take ten minutes at 2 M rows per shard)
-        msamp = min(n, 100_000)
+        msamp = n_cal
         with tempfile.TemporaryDirectory() as d:
             shard_files = []  # (NOT `names`: that is the list of round names the JSON line is keyed by below)
             for r in range(world):
@@ -516,6 +610,9 @@ def multi_gpu(args: argparse.Namespace, world: int) -> None:
                             "round in bins of 10, tolerance-diameter merges); timed region = run_multiround_distributed "
                             "(round 1, RCCL exchange of the BitFeature tables to the merging ranks, merge round, exchange to "
                             "rank 0, final merge) + cluster labels",
+                "rows_per_shard": n,
+                "rows_per_shard_stated": PLAN_STATED_ROWS,
+                "plan": plan,
                 "clusters": state.get("clusters"),
                 "labelled": None if labels is None else int(labels.size),
                 "rccl_ranks": dist.get_world_size(),
@@ -541,6 +638,11 @@ def multi_gpu(args: argparse.Namespace, world: int) -> None:
             },
             "cpu_baseline": cpu_mr,
         }
+        if cpu_mr is not None:
+            # like for like: the GPU job on the very rows the CPU baseline was timed on - small trees on both sides;
+            # `value` above is the job at `rows_per_shard`, whose per-row cost differs (larger trees), so no ratio is formed from it
+            cpu_mr["gpu_on_same_sample"] = {"rows_per_shard": n_cal, "fingerprints_per_s": world * n_cal / t_cal,
+                                            "gpu_over_cpu": (world * n_cal / t_cal) / cpu_mr["value"] if cpu_mr.get("value") else None}
         _emit(out)
     dist.barrier()
     dist.destroy_process_group()
@@ -797,13 +899,17 @@ def single_gpu(args: argparse.Namespace) -> None:
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     reps = 10
-    e0.record()
-    for _ in range(reps):
-        _jt_sim_arr_vec_packed(big, vec)
-    e1.record()
-    torch.cuda.synchronize()
-    k1_ms = e0.elapsed_time(e1) / reps
+    k1_runs = []
+    for _ in range(3):  # (three repeats: the regression guard lists an entry only when two of three are worse)
+        e0.record()
+        for _ in range(reps):
+            _jt_sim_arr_vec_packed(big, vec)
+        e1.record()
+        torch.cuda.synchronize()
+        k1_runs.append(e0.elapsed_time(e1) / reps)
+    k1_ms = sorted(k1_runs)[1]
     k1_gbs = BYTES_PER_FP * k1_rows / (k1_ms * 1e-3) / 1e9
+    k1_repeats = [BYTES_PER_FP * k1_rows / (m_ * 1e-3) / 1e9 for m_ in k1_runs]
     # K2 (batched descent step: every query row against all centroids of a node, exact first-argmax):
     # VALU-bound - 2 ops (AND, BCNT) per query dword and centroid row on 256 CUs x 64 lanes
     nq2, nc2 = min(k1_rows, 4_000_000), args.bf + 1  # enough queries to hide the launch tail
@@ -864,7 +970,8 @@ def single_gpu(args: argparse.Namespace) -> None:
 
         host = fps.cpu().numpy()
         per = n // args.multiround_files
-        with tempfile.TemporaryDirectory() as d:
+        shm = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None  # (memory-backed: the box's disk is not the subject)
+        with tempfile.TemporaryDirectory(dir=shm) as d:
             names = []
             for i in range(args.multiround_files):
                 f = Path(d) / f"fps.{i:05d}.npy"
@@ -872,12 +979,21 @@ def single_gpu(args: argparse.Namespace) -> None:
                 names.append(f)
             out_dir = Path(d) / "out"
             out_dir.mkdir()
+            lib.bbh_profile_enable(1)
+            lib.bbh_profile_reset()
             t1 = time.perf_counter()
             timer = run_multiround_bitbirch(names, out_dir, branching_factor=args.bf, threshold=args.threshold,
                                             num_initial_processes=1, device=local_rank)
             dt = time.perf_counter() - t1
+            _, mr_kernel_ms, _ = _profile(lib, b"tree_insert")
+            lib.bbh_profile_enable(0)
             mr_stats = {"files": args.multiround_files, "rows": per * args.multiround_files, "seconds": dt,
-                        "fingerprints_per_s": per * args.multiround_files / dt,
+                        "wall_fingerprints_per_s": per * args.multiround_files / dt,
+                        # what the regression guard compares: the summed HIP-event time of the tree kernels' launches; the rest of
+                        # the wall time is the reference's file formats (.npy tables, pickled member lists) on whatever the box offers
+                        "kernel_s": mr_kernel_ms * 1e-3, "io_and_host_s": dt - mr_kernel_ms * 1e-3,
+                        "kernel_fingerprints_per_s": per * args.multiround_files / (mr_kernel_ms * 1e-3) if mr_kernel_ms > 0 else None,
+                        "files_on": "/dev/shm" if shm else "tmp",
                         "rounds_s": {k: round(v, 3) for k, v in timer.timings.items()},
                         "note": "file-compatible multiround with the reference's defaults (full refinement, one merge "
                                 "round in bins of 10, tolerance-diameter merges); files on tmpfs/disk inside the timing"}
@@ -890,6 +1006,7 @@ def single_gpu(args: argparse.Namespace) -> None:
     # the rank path (what --gpus N times) on this one GPU: 8 shards of n / 8 rows resident in HBM through
     # run_multiround_distributed with one RCCL rank (round 1, table "exchange" on the device, merge round, final merge, labels)
     dist_one = None
+    scale_anchor = None
     if not args.no_extras:
         try:
             import torch.distributed as dist
@@ -913,6 +1030,29 @@ def single_gpu(args: argparse.Namespace) -> None:
                     pass
                 os.dup2(saved_fd, 1)
                 os.close(saved_fd)
+            # (a) SCALE anchor: the `--gpus N` job with ONE shard on ONE RCCL rank - same generator, branching
+            # factor, rows per shard (sized by plan_multi for this --steps / --warmup, as every N is), CLI defaults - so that the
+            # driver's 1 -> N curve compares equal work per GPU; the `--gpus 1` headline above is a different job (one tree, bf 50).
+            plan = plan_multi(1, args.steps, args.warmup)
+            a_rows = plan["rows_per_shard"]
+            a_gen, a_thr, _ = WORKLOADS["ecfp"]
+            a_shard = a_gen(a_rows, 1000, dev)
+            torch.cuda.synchronize()
+            run_multiround_distributed([a_shard[:100_000]], None, branching_factor=254, threshold=a_thr, device=local_rank, return_tree=True)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            atree, atimer = run_multiround_distributed([a_shard], None, branching_factor=254, threshold=a_thr, device=local_rank,
+                                                       return_tree=True)
+            alabels = atree.get_assignments()
+            a_dt = time.perf_counter() - t1
+            scale_anchor = {"value": a_rows / a_dt, "unit": "fingerprints/s", "n_gpus": 1, "rccl_ranks": 1, "seconds": a_dt,
+                            "rows_per_shard": a_rows, "workload": "ecfp", "branching_factor": 254, "threshold": a_thr,
+                            "clusters": int(alabels.max()), "rounds_s": {k: round(float(v), 3) for k, v in atimer.timings.items()},
+                            "plan": plan,
+                            "note": "the job `bench.py --gpus N` times (BASELINE configs[3] shape: multiround, one S-ecfp shard per GPU, "
+                                    "bf 254, CLI defaults, labels included) with N = 1: the like-for-like 1-GPU point of the scaling curve"}
+            del atree, alabels, a_shard
+            # (b) the rank path on the HEADLINE rows: 8 shards of n / 8 rows resident in HBM, one RCCL rank
             per = n // 8
             parts = [fps[i * per:(i + 1) * per] for i in range(8)]
             torch.cuda.synchronize()
@@ -1010,6 +1150,7 @@ def single_gpu(args: argparse.Namespace) -> None:
             "frac": k1_gbs / HBM_PEAK_GBS,
             "rows": k1_rows,
             "avg_launch_ms": k1_ms,
+            "achieved_repeats": k1_repeats,
         },
         "k2_valu": {
             "kernel": "k_best_match<64> (batched node compare, exact first-argmax)",
@@ -1026,6 +1167,7 @@ def single_gpu(args: argparse.Namespace) -> None:
         "merge_round": merge_round,
         "bf1000": bf1000,
         "cpu_baseline_bf254": cpu254,
+        "scale_anchor": scale_anchor,
         "distributed_one_rank": dist_one,
         "concurrent_shards": shard_stats,
         "multiround_one_gpu": mr_stats,
@@ -1037,7 +1179,8 @@ def single_gpu(args: argparse.Namespace) -> None:
     else:
         out["cpu_baseline"] = None
     if args.workload == "fake" and n == 1_000_000 and args.bf == 50:
-        out["regressions"] = regressions(out, REPO / "profiles" / PREVIOUS_ROUND / "bench_line_final.json")
+        out["regressions"] = regressions(out, [REPO / "profiles" / PREVIOUS_ROUND / "bench_line_final.json",
+                                               REPO / f"BENCH_{PREVIOUS_ROUND}.json"])
     _emit(out)
 
 
