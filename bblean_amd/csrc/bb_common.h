@@ -68,6 +68,7 @@ int ensure_device();  // picks device 0 lazily, checks it is gfx950
 hipError_t dev_alloc(void** p, size_t bytes);
 void dev_free(void* p);
 void dev_trim();
+hipError_t dev_free_bytes(size_t need, size_t* free_b);  // hipMemGetInfo's free bytes; caches are emptied first when that is less than `need`
 void set_pressure_callback(void (*fn)(void));  // called when hipMalloc fails, before the one retry (bbh_set_memory_pressure_callback)
 template <typename T>
 inline hipError_t dev_alloc(T** p, size_t bytes) { return dev_alloc((void**)p, bytes); }

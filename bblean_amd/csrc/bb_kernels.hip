@@ -96,6 +96,19 @@ DevCache& dev_cache() {
 static std::atomic<void (*)(void)> g_pressure_cb{nullptr};
 void set_pressure_callback(void (*fn)(void)) { g_pressure_cb.store(fn); }
 
+// Free device memory as far as a growing pool may count on it: when the driver reports less than `need` free, the blocks
+// this library's cache retains and the host side's (the Python shim registers torch.cuda.empty_cache) are given back first
+// and the driver is asked again (gc_nodes / fit_to_memory clamped or refused a pool on the first answer, while
+// gigabytes sat in caches that only a FAILED hipMalloc would have emptied).
+hipError_t dev_free_bytes(size_t need, size_t* free_b) {
+    size_t total_b = 0;
+    hipError_t e = hipMemGetInfo(free_b, &total_b);
+    if (e != hipSuccess || *free_b >= need) return e;
+    dev_trim();
+    if (void (*cb)(void) = g_pressure_cb.load()) cb();
+    return hipMemGetInfo(free_b, &total_b);
+}
+
 hipError_t dev_alloc(void** p, size_t bytes) {
     DevCache& c = dev_cache();
     int dev = 0;

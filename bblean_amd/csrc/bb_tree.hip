@@ -1831,8 +1831,8 @@ __device__ __forceinline__ void tree_insert_body(unsigned char* smem_raw, TreeDe
                     if (hw_cap(leaf) < k.rows) {
                         // a sealed node: nothing is written to it where it lies (bb_tree.hip, "Node storage")
                         if constexpr (SUB) { bad = true; break; }  // (concurrent gates: the host thaws the whole tree first)
-                        const uint32_t pP = depth > 0 ? uni(path_node[depth - 1]) : NONE, pj = depth > 0 ? uni(path_row[depth - 1]) : 0u;
                         __syncthreads();  // (path_node / path_row of the level above were written by thread 0)
+                        const uint32_t pP = depth > 0 ? uni(path_node[depth - 1]) : NONE, pj = depth > 0 ? uni(path_row[depth - 1]) : 0u;
                         nd = thaw_node(k, nd, pP, pj, cN, cRoot, cFirst);
 #pragma unroll
                         for (int q = 0; q < MAXM; ++q) mir_node[q] = NONE;  // (the parent's mirror holds the old child id)
@@ -2608,8 +2608,9 @@ static uint32_t fit_to_memory(uint32_t want, uint32_t floor_elems, uint32_t cap,
     // (hipMemGetInfo is a driver call of tens of microseconds: a round of 512 small shard trees made 2 048 of them, most of
     // what bench.py's `concurrent_shards` lost between rounds 3 and 4 in a fresh process - small requests are not clamped)
     if ((uint64_t)want * elem_bytes < (256ull << 20)) return want;
-    size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return want; }
+    size_t free_b = 0;
+    // (caches - this library's and the host side's - are emptied before the answer is taken for the truth: ADVICE r5)
+    if (bb::dev_free_bytes((size_t)((double)want * (double)elem_bytes / 0.9) + 1, &free_b) != hipSuccess) { (void)hipGetLastError(); return want; }
     // (the copying growth holds the old pool until the new one is filled: only the free memory counts)
     const size_t room = (size_t)((double)free_b * 0.9) / std::max<size_t>(elem_bytes, 1);
     // (a pool that the free memory only lets grow by the floor - a few dozen elements - would be copied whole every
@@ -2728,8 +2729,10 @@ int gc_nodes(bbh_tree* t, uint64_t extra, int seal) {
         const uint64_t floor_b = (uint64_t)total + (2 * (uint64_t)h.ctr[C_DEPTH] + 8) * node_blocks(rows);
         uint64_t want = (uint64_t)total + std::max<uint64_t>(extra, tiny_pools() ? 0 : (uint64_t)total / 4);
         want = std::max(want, floor_b);
-        size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+        size_t free_b = 0;
+        // (what is free AFTER the caches - this library's and, through the memory-pressure callback, the host side's - have been
+        // emptied, if the first answer is short of `want`: ADVICE r5)
+        if (bb::dev_free_bytes((size_t)((double)want * (double)block_bytes(h) / 0.92) + 1, &free_b) == hipSuccess) {
             const uint64_t room = (uint64_t)((double)free_b * 0.92) / block_bytes(h);
             if (want > room) {
                 // (near the end of the device's memory the pool takes what is left - but not in steps so small that every few
@@ -2963,7 +2966,9 @@ static bool dense_launch(size_t n_trees, size_t lds_bytes) {
 int pregrow(bbh_tree* t, int64_t n, int width) {
     TreeDev& h = t->h;
     const bool first = t->lazy_pools;  // the tree's pools come into being here: every pool at least at its minimum
-    t->lazy_pools = false;
+    // (lazy_pools is cleared only when every first allocation has succeeded - ADVICE r5: a tree whose first fit ran out of
+    // memory must still read as "owns no pools" to build_chain / export / compact)
+    struct Commit { bbh_tree* t; bool ok = false; ~Commit() { if (ok) t->lazy_pools = false; } } commit{t};
     if (first && tiny_pools()) {
         BB_TRY(grow_cf(t, 0, 8));
         BB_TRY(grow_cf(t, 1, 8));
@@ -2974,6 +2979,7 @@ int pregrow(bbh_tree* t, int64_t n, int width) {
         BB_TRY(grow_cf(t, 1, clamp30((uint64_t)h.ctr[C_N16] + 8)));
         BB_TRY(grow_nodes(t, clamp30((uint64_t)h.ctr[C_NODES] + (8 + 2 * (uint64_t)h.ctr[C_DEPTH]) * node_blocks((uint32_t)h.bf + 1))));
         BB_TRY(grow_cf(t, 2, clamp30((uint64_t)h.ctr[C_N32] + 16 + 2 * (uint64_t)h.ctr[C_DEPTH])));
+        commit.ok = true;
         return BBH_OK;
     }
     const uint64_t un = (uint64_t)std::max<int64_t>(n, 0);
@@ -2981,6 +2987,7 @@ int pregrow(bbh_tree* t, int64_t n, int width) {
     if (width == 2 || first) BB_TRY(grow_cf(t, 1, clamp30((uint64_t)h.ctr[C_N16] + (width == 2 ? un : 0) + 64)));
     BB_TRY(grow_nodes(t, clamp30((uint64_t)h.ctr[C_NODES] + (un / (uint64_t)std::max(1, h.bf / 2) + 64) * node_blocks((uint32_t)h.bf + 1))));
     BB_TRY(grow_cf(t, 2, clamp30((uint64_t)h.ctr[C_N32] + un / (uint64_t)std::max(1, h.bf / 6) + 256)));
+    commit.ok = true;
     return BBH_OK;
 }
 

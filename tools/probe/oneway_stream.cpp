@@ -21,6 +21,7 @@
 #include <cstdio>
 #include <cstdint>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s -> %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
@@ -28,7 +29,7 @@
 typedef unsigned long long u64;
 constexpr int R = 1024;        // ring entries (16 B each)
 constexpr int MAXG = 64;       // producers a consumer polls with one wave-wide load
-constexpr u64 SPIN_LIMIT = 400000000ull;  // cycles before a wait gives up (never hang the box)
+constexpr u64 SPIN_LIMIT = 2400000000ull;  // s_memtime ticks (shader clock, ~2.4 GHz: ~2 s) before a wait gives up (never hang the box; 0.17 s tripped once on a loaded run)
 
 struct Params {
     u64* rings;        // [consumer][producer][R][2]
@@ -38,6 +39,8 @@ struct Params {
     uint32_t* arrived;    // [N] at the last stage
     uint32_t* errors;
     uint32_t* diag;
+    u64* diag64;       // first timeout: what the waiting side saw
+    u64* state;        // [wg][4]: phase word (where thread 0 is), elements taken, exit reason, last element
     const uint8_t* rows;  // element rows (256 B each), N_ROWS of them
     u64* sink;
     int n_rows;
@@ -47,6 +50,8 @@ struct Params {
     int first[8];       // first workgroup id of a stage (in units of `stride`)
     int stride;         // 1: stages dealt round-robin over the XCDs; 8: everything on one XCD
     int work;           // 0 none, 1 row + 51-row compare
+    int poll;           // 0: relaxed agent-scope (sc1) loads only; 1: + an agent-scope acquire fence (buffer_inv sc1) after every poll that
+                        // found nothing; 2: system-scope (sc0 sc1) loads
 };
 
 __device__ __forceinline__ u64 ld_sc1(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -78,9 +83,13 @@ __global__ __launch_bounds__(256) void k_stream(Params P) {
     const uint32_t my_share_end = (uint32_t)P.n_elems;
     uint32_t next_elem = 0;  // stage 0 only
     u64 t_last = __builtin_amdgcn_s_memtime();
+    u64 taken = 0;
+    int exit_reason = 0;
+#define MARK(ph) do { if (tid == 0) st_sc1(P.state + (size_t)wg * 4, ((u64)(ph) << 32) | (uint32_t)taken); } while (0)
     while (true) {
         // ---- get the next element --------------------------------------------------------------
         uint32_t elem = 0xFFFFFFFFu, from = 0;
+        MARK(1);
         if (stage == 0) {
             if (next_elem >= my_share_end) break;
             elem = next_elem++;
@@ -91,8 +100,13 @@ __global__ __launch_bounds__(256) void k_stream(Params P) {
                 bool ready = false;
                 while (true) {
                     if (lane < nprod) {
-                        a = ld_sc1(slot);
-                        b = ld_sc1(slot + 1);
+                        if (P.poll == 2) {
+                            a = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                            b = __hip_atomic_load(slot + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        } else {
+                            a = ld_sc1(slot);
+                            b = ld_sc1(slot + 1);
+                        }
                         const u64 gen = ((head / R) + 1) & 1;
                         ready = (a >> 63) == gen && (b >> 63) == gen;
                     }
@@ -113,17 +127,32 @@ __global__ __launch_bounds__(256) void k_stream(Params P) {
                     const uint32_t ab = __hip_atomic_load(P.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (ab != 0) { if (lane == 0) s_msg[0] = 0xFFFFFFFFu; break; }
                     if (__builtin_amdgcn_s_memtime() - t_last > SPIN_LIMIT) {
-                        if (lane == 0) { atomicAdd(P.errors, 1000000u); __hip_atomic_store(P.abort_flag, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); s_msg[0] = 0xFFFFFFFFu; }
+                        // what does the slot look like now - through the same sc1 loads, after an agent-scope acquire, and at system scope?
+                        uint32_t first = 0;
+                        if (lane == 0) first = atomicAdd(P.errors, 1000000u);
+                        first = __shfl(first, 0);
+                        if (lane < nprod && lane < 2) {  // (every workgroup that gives up: the one whose view is stale is not the first)
+                            u64* dg = P.diag64 + ((size_t)wg * 2 + lane) * 8;
+                            dg[0] = ((u64)stage << 48) | ((u64)me << 32) | head;
+                            dg[1] = a; dg[2] = b;
+                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                            dg[3] = ld_sc1(slot); dg[4] = ld_sc1(slot + 1);
+                            dg[5] = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                            dg[6] = __hip_atomic_load(slot + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                            dg[7] = 1;
+                        }
+                        if (lane == 0) { __hip_atomic_store(P.abort_flag, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); s_msg[0] = 0xFFFFFFFFu; }
                         break;
                     }
-                    __builtin_amdgcn_s_sleep(1);
+                    if (P.poll == 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    else __builtin_amdgcn_s_sleep(1);
                 }
             }
             __syncthreads();
             elem = s_msg[0];
             from = s_msg[1];
             __syncthreads();
-            if (elem == 0xFFFFFFFFu) break;
+            if (elem == 0xFFFFFFFFu) { exit_reason = 1; break; }
             // order per producer
             if (tid == 0 && stage <= 2) {
                 uint32_t* ls = P.last_seen + (size_t)(P.first[stage] + me) * MAXG + from;
@@ -135,6 +164,8 @@ __global__ __launch_bounds__(256) void k_stream(Params P) {
                 *ls = elem + 1;
             }
         }
+        taken++;
+        MARK(2);
         // ---- the stage's own work ------------------------------------------------------------------
         if (P.work) {
             const uint32_t r = hash32(elem) % (uint32_t)P.n_rows;
@@ -151,6 +182,7 @@ __global__ __launch_bounds__(256) void k_stream(Params P) {
             __syncthreads();
         }
         // ---- hand over -----------------------------------------------------------------------------
+        MARK(3);
         if (last) {
             if (tid == 0) {
                 atomicAdd(P.arrived + elem, 1u);
@@ -163,11 +195,16 @@ __global__ __launch_bounds__(256) void k_stream(Params P) {
                 if (tail - cons_seen >= (uint32_t)(R - 64)) {
                     const u64 t0 = __builtin_amdgcn_s_memtime();
                     while (true) {
-                        cons_seen = __hip_atomic_load(P.consumed + (size_t)cw * MAXG + me, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (P.poll == 2) cons_seen = __hip_atomic_load(P.consumed + (size_t)cw * MAXG + me, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        else cons_seen = __hip_atomic_load(P.consumed + (size_t)cw * MAXG + me, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         if (tail - cons_seen < (uint32_t)(R - 64)) break;
+                        if (P.poll == 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                         if (__builtin_amdgcn_s_memtime() - t0 > SPIN_LIMIT ||
                             __hip_atomic_load(P.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 2u) {
-                            atomicAdd(P.errors, 1000000u);
+                            if (atomicAdd(P.errors, 1000000u) < 1000000u) {
+                                u64* dg = P.diag64 + 512 * 8;
+                                dg[0] = ((u64)stage << 48) | ((u64)me << 32) | tail; dg[1] = ((u64)c << 32) | cons_seen; dg[7] = 2;
+                            }
                             __hip_atomic_store(P.abort_flag, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             break;
                         }
@@ -182,6 +219,8 @@ __global__ __launch_bounds__(256) void k_stream(Params P) {
         }
     }
     if (tid == 0) {
+        P.state[(size_t)wg * 4 + 1] = taken;
+        P.state[(size_t)wg * 4 + 2] = 100 + exit_reason;
         P.sink[blockIdx.x] = acc;
     }
 }
@@ -202,6 +241,10 @@ __global__ void k_watch(uint32_t* errors, uint32_t* abort_flag, uint32_t n) {
 int main(int argc, char** argv) {
     setvbuf(stdout, nullptr, _IONBF, 0);
     const int N = argc > 1 ? atoi(argv[1]) : 400000;
+    const int REPS = argc > 2 ? atoi(argv[2]) : 2;
+    const int ONLY_WORK = argc > 3 ? atoi(argv[3]) : -1;
+    const char* ONLY_CFG = argc > 4 ? argv[4] : nullptr;
+    const int POLL = argc > 5 ? atoi(argv[5]) : 1;
     const int NROWS = 65536;
     const size_t total_wg = 256;
     u64* rings; uint32_t *consumed, *abort_flag, *last_seen, *arrived, *errors, *diag; uint8_t* rows; u64* sink;
@@ -213,6 +256,10 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&arrived, (size_t)N * 4));
     CK(hipMalloc(&errors, 8));
     CK(hipMalloc(&diag, 32 * 4));
+    u64* diag64;
+    CK(hipMalloc(&diag64, 513 * 8 * 8));
+    u64* state;
+    CK(hipMalloc(&state, 2048 * 4 * 8));
     CK(hipMalloc(&rows, (size_t)NROWS * 256));
     CK(hipMalloc(&sink, 2048 * 8));
     std::vector<uint8_t> h((size_t)NROWS * 256);
@@ -235,21 +282,24 @@ int main(int argc, char** argv) {
         {"1 -> 4 -> 16 -> 64 (root, two levels, leaves)", 4, {1, 4, 16, 64}},
         {"1 -> 16 -> 32 -> 64", 4, {1, 16, 32, 64}},
     };
+    printf("poll mode %d (0: sc1 loads; 1: + agent acquire fence after an empty poll; 2: system-scope loads), %d elements, %d repeats\n", POLL, N, REPS);
     printf("%-48s %6s %5s | %10s %10s  %s\n", "stages (workgroups per stage)", "stride", "work", "M msgs/s", "us/elem", "check");
     for (const Cfg& c : cfgs)
-        for (int stride : {1, 8})
+        for (int stride : {1, 8}) {
+            if (ONLY_CFG && std::strcmp(c.name, ONLY_CFG) != 0) continue;
             for (int work : {0, 1}) {
+                if (ONLY_WORK >= 0 && work != ONLY_WORK) continue;
                 Params P{};
                 P.rings = rings; P.consumed = consumed; P.abort_flag = abort_flag; P.last_seen = last_seen; P.arrived = arrived;
-                P.errors = errors; P.diag = diag; P.rows = rows; P.sink = sink; P.n_rows = NROWS; P.n_elems = N; P.stages = c.stages;
+                P.errors = errors; P.diag = diag; P.diag64 = diag64; P.state = state; P.rows = rows; P.sink = sink; P.n_rows = NROWS; P.n_elems = N; P.stages = c.stages;
                 int f = 0;
                 for (int i = 0; i < c.stages; ++i) { P.k[i] = c.k[i]; P.first[i] = f; f += c.k[i]; }
-                P.stride = stride; P.work = work;
+                P.stride = stride; P.work = work; P.poll = POLL;
                 if ((size_t)f * stride > 2048 || (stride == 8 && f > 32)) continue;  // one XCD has 32 CUs
                 float best = 1e30f;
                 uint32_t herr[2] = {0, 0};
                 bool ok = true;
-                for (int rep = 0; rep < 2; ++rep) {
+                for (int rep = 0; rep < REPS; ++rep) {
                     CK(hipMemset(rings, 0, ring_bytes));
                     CK(hipMemset(consumed, 0, total_wg * MAXG * 4));
                     CK(hipMemset(abort_flag, 0, 4));
@@ -257,6 +307,8 @@ int main(int argc, char** argv) {
                     CK(hipMemset(arrived, 0, (size_t)N * 4));
                     CK(hipMemset(errors, 0, 8));
                     CK(hipMemset(diag, 0, 32 * 4));
+                    CK(hipMemset(diag64, 0, 513 * 8 * 8));
+                    CK(hipMemset(state, 0, 2048 * 4 * 8));
                     CK(hipDeviceSynchronize());
                     CK(hipEventRecord(e0, s1));
                     hipLaunchKernelGGL(k_stream, dim3(f * stride), dim3(256), 0, s1, P);
@@ -275,6 +327,20 @@ int main(int argc, char** argv) {
                     if (bad || herr[0]) ok = false;
                     if (bad || herr[0]) {
                         printf("   (rep %d: %zu elements not delivered exactly once, order/timeouts word %u, reached end %u)\n", rep, bad, herr[0], herr[1]);
+                        std::vector<u64> h64(513 * 8);
+                        CK(hipMemcpy(h64.data(), diag64, 513 * 8 * 8, hipMemcpyDeviceToHost));
+                        for (int q = 0; q < 513; ++q)
+                            if (h64[q * 8 + 7] == 1)
+                                printf("      consumer timeout: stage %llu me %llu [wg*2+producer %d] head %llu (slot %llu, expected gen %llu): saw %016llx %016llx, after acquire %016llx %016llx, system scope %016llx %016llx\n",
+                                       h64[q * 8] >> 48, (h64[q * 8] >> 32) & 0xFFFF, q, h64[q * 8] & 0xFFFFFFFFull, (h64[q * 8] & 0xFFFFFFFFull) % R,
+                                       (((h64[q * 8] & 0xFFFFFFFFull) / R) + 1) & 1, h64[q * 8 + 1], h64[q * 8 + 2], h64[q * 8 + 3], h64[q * 8 + 4], h64[q * 8 + 5], h64[q * 8 + 6]);
+                            else if (h64[q * 8 + 7] == 2)
+                                printf("      producer timeout: stage %llu wg %llu tail %llu -> consumer %llu, consumed seen %llu\n", h64[q * 8] >> 48,
+                                       (h64[q * 8] >> 32) & 0xFFFF, h64[q * 8] & 0xFFFFFFFFull, h64[q * 8 + 1] >> 32, h64[q * 8 + 1] & 0xFFFFFFFFull);
+                        std::vector<u64> hs(2048 * 4);
+                        CK(hipMemcpy(hs.data(), state, hs.size() * 8, hipMemcpyDeviceToHost));
+                        for (int w = 0; w < f; ++w)
+                            printf("      wg %3d: phase %llu taken(mark) %llu taken(exit) %llu exit %llu\n", w, hs[w * 4] >> 32, hs[w * 4] & 0xFFFFFFFFull, hs[w * 4 + 1], hs[w * 4 + 2]);
                         uint32_t hd[32];
                         CK(hipMemcpy(hd, diag, sizeof(hd), hipMemcpyDeviceToHost));
                         for (int q = 0; q < 8 && q < (int)(herr[0] % 1000000u); ++q)
@@ -283,5 +349,6 @@ int main(int argc, char** argv) {
                 }
                 printf("%-48s %6d %5d | %10.3f %10.3f  %s\n", c.name, stride, work, N / (best * 1e3), best * 1e3 / N, ok ? "ok" : "FAILED");
             }
+        }
     return 0;
 }
