@@ -374,6 +374,14 @@ class HipEngine:
         _lib.check(self._lib.bbh_tree_kernel_counts(self._h, out.ctypes.data))
         return out
 
+    def sys_counts(self) -> NDArray[np.uint64]:
+        r"""The level-systolic kernel (one tree over many workgroups): [0] elements, [1] launches, [2] relaunches after a root
+        split, [3] workgroups, [4] busy shader cycles of all its workgroups, [5] of workgroup 0, [6] of the busiest other
+        workgroup, [7] launches it refused."""
+        out = np.zeros(8, dtype=np.uint64)
+        _lib.check(self._lib.bbh_tree_sys_counts(self._h, out.ctypes.data))
+        return out
+
     def memory(self) -> NDArray[np.uint64]:
         r"""[0] node pools (bytes, capacity), [1] their used part, [2] cluster-feature pools, [3] peak of this tree's
         allocations, [4] compactions of the node pools, [5] / [6] nodes the last one sealed / left at full capacity,

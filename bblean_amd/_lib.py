@@ -63,6 +63,7 @@ _PROTOTYPES = {
     "bbh_tree_gather_centroids": (_int, [_vp, _vp, _i64, _vp]),
     "bbh_tree_stats": (_int, [_vp, _vp]),
     "bbh_tree_kernel_counts": (_int, [_vp, _vp]),
+    "bbh_tree_sys_counts": (_int, [_vp, _vp]),
     "bbh_tree_memory": (_int, [_vp, _vp]),
     "bbh_tree_compact": (_int, [_vp, _i32]),
     "bbh_profile_enable": (_int, [_int]),

@@ -2224,6 +2224,7 @@ __global__ __launch_bounds__(TB, 2) void k_tree_insert_dense(TreeDev* trees) {
 #endif  // __HIPCC__ (bb_tree_fast.inc has its own host / device split)
 #include "bb_tree_fast.inc"
 #include "bb_tree_pipe.inc"
+#include "bb_tree_sys.inc"
 #if defined(__HIPCC__)
 
 // the complete engine compiled for the benchmark shape with phase timers (tools/phases.py with BBHIP_NO_FAST=1)
@@ -2564,6 +2565,15 @@ struct bbh_tree {
     bool lazy_pools = false;  // a fresh tree owns no pools yet: the first call that inserts allocates them at the size it needs (pregrow)
     bool no_seal = false;  // (while the exact batch mode runs: compactions leave every node at full capacity)
     size_t peak_bytes = 0;  // largest sum of this tree's pool allocations (both copies of a pool that is being regrown included)
+    // the level-systolic kernel (bb_tree_sys.inc): its work area in HBM (rings, mailboxes), how many blocks the mailbox arrays hold,
+    // and what it did: elements, launches, relaunches after a root split, workgroups of the last launch, summed busy cycles of
+    // all workgroups / of workgroup 0, launches it refused (bbh_tree_sys_counts)
+    SysDev sys{};
+    size_t sys_ring_bytes = 0;
+    uint32_t sys_cap_nodes = 0;
+    int sys_G_alloc = 0;
+    uint64_t syscount[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int64_t sys_off_left = 0;  // elements the other kernels take after the systolic one refused the tree
 };
 
 namespace {
@@ -2934,6 +2944,8 @@ int configure(bbh_tree* t, int32_t bf, int32_t n_features) {
                 return bb::fail(BBH_ERR_NO_DEVICE, "device %d offers %d bytes of LDS per workgroup, the tree kernels need %u", t->device, cap,
                                 pipe_layout(254).total);
             }
+            BB_HIP(hipFuncSetAttribute((const void*)k_tree_sys<KS50>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(KS50::o.total + SYS_LDS_BYTES)));
+            BB_HIP(hipFuncSetAttribute((const void*)k_tree_sys<KS254>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(KS254::o.total + SYS_LDS_BYTES)));
             attr_done_dev[di] = true;
         }
     }
@@ -3012,6 +3024,92 @@ struct Job {
     int stalls;
     int64_t old_left = 0;  // elements the steady-state kernel takes next (the pipelined one reported a shape it does not handle)
 };
+
+// ---- the level-systolic kernel's work area and launch plan (bb_tree_sys.inc) --------------------------------------------
+void sys_free(bbh_tree* t) {
+    void* ptrs[] = {t->sys.rings, t->sys.mail, t->sys.sent, t->sys.up, t->sys.ctl, t->sys.busy};
+    for (void* q : ptrs)
+        if (q) bb::dev_free(q);
+    t->sys = SysDev{};
+    t->sys_ring_bytes = 0;
+    t->sys_cap_nodes = 0;
+    t->sys_G_alloc = 0;
+}
+
+// BBHIP_SYS: "0" never, "1" whenever the tree's shape allows it, unset / "auto": where the other kernels are weakest (see
+// sys_wanted).  Read on every call: tests switch it inside one process.
+static int sys_mode() {
+    const char* v = getenv("BBHIP_SYS");
+    if (v == nullptr || v[0] == '\0' || std::strcmp(v, "auto") == 0) return 2;
+    return std::strcmp(v, "0") == 0 ? 0 : 1;
+}
+
+// workgroups per tree level: level 0 is workgroup 0 (the root), the last level the leaf owners
+static void sys_plan(const TreeDev& h, SysDev& S) {
+    const int levels = (int)h.ctr[C_DEPTH];  // (1: the root is a leaf)
+    S.levels = levels;
+    int first = 0;
+    static const int env_int = [] { const char* v = getenv("BBHIP_SYS_INTERNAL_WGS"); return v ? atoi(v) : 0; }();
+    static const int env_leaf = [] { const char* v = getenv("BBHIP_SYS_LEAF_WGS"); return v ? atoi(v) : 0; }();
+    for (int l = 0; l < levels && l < SYS_MAXLVL; ++l) {
+        int cnt;
+        if (l == 0) cnt = 1;
+        else if (l == levels - 1) cnt = env_leaf > 0 ? env_leaf : 64;
+        else cnt = env_int > 0 ? env_int : (h.bf >= 128 ? 32 : 16);
+        cnt = std::min(cnt, SYS_MAXPROD);
+        S.lvl_first[l] = first;
+        S.lvl_count[l] = cnt;
+        first += cnt;
+    }
+    S.G = first;
+    S.R = 1024;
+    S.qmax = 384;
+}
+
+// (re)allocate what the plan and the node pool's size need; zero the rings and control words, initialise the mailboxes
+static int sys_prepare(bbh_tree* t, hipStream_t s) {
+    TreeDev& h = t->h;
+    SysDev& S = t->sys;
+    sys_plan(h, S);
+    {
+        // the kernel admits an element only while the pools hold the worst case of everything in flight (every element splits
+        // every level and the root): make sure a launch starts with that reserve and room to work in
+        const uint64_t q = (uint64_t)S.qmax + 64, depth = h.ctr[C_DEPTH], nblk = node_blocks((uint32_t)h.bf + 1);
+        const uint64_t room = tiny_pools() ? 16 : 4096;  // (elements' worth of room beyond the reserve)
+        BB_TRY(grow_nodes(t, clamp30((uint64_t)h.ctr[C_NODES] + (q * (depth + 2) + room / 8 + 8) * nblk)));
+        BB_TRY(grow_cf(t, 0, clamp30((uint64_t)h.ctr[C_N8] + q + room)));
+        BB_TRY(grow_cf(t, 1, clamp30((uint64_t)h.ctr[C_N16] + q + 64)));
+        BB_TRY(grow_cf(t, 2, clamp30((uint64_t)h.ctr[C_N32] + q * 2 * (depth + 2) + room / 4 + 16)));
+    }
+    const size_t ring_bytes = (size_t)S.G * SYS_MAXPROD * (size_t)S.R * 16;
+    if (ring_bytes > t->sys_ring_bytes || S.G > t->sys_G_alloc) {
+        if (S.rings) bb::dev_free(S.rings);
+        if (S.busy) bb::dev_free(S.busy);
+        S.rings = nullptr; S.busy = nullptr;
+        BB_HIP(bb::dev_alloc(&S.rings, ring_bytes));
+        BB_HIP(bb::dev_alloc(&S.busy, (size_t)S.G * 8 + 64));
+        t->sys_ring_bytes = ring_bytes;
+        t->sys_G_alloc = S.G;
+    }
+    if (!S.ctl) BB_HIP(bb::dev_alloc(&S.ctl, SC_COUNT * 4));
+    if (h.cap_nodes > t->sys_cap_nodes || !S.mail) {
+        if (S.mail) bb::dev_free(S.mail);
+        if (S.sent) bb::dev_free(S.sent);
+        if (S.up) bb::dev_free(S.up);
+        S.mail = nullptr; S.sent = nullptr; S.up = nullptr;
+        BB_HIP(bb::dev_alloc(&S.mail, (size_t)h.cap_nodes * 8 + 64));
+        BB_HIP(bb::dev_alloc(&S.sent, (size_t)h.cap_nodes * 4 + 64));
+        BB_HIP(bb::dev_alloc(&S.up, (size_t)h.cap_nodes * 8 + 64));
+        t->sys_cap_nodes = h.cap_nodes;
+    }
+    BB_HIP(hipMemsetAsync(S.rings, 0, ring_bytes, s));
+    BB_HIP(hipMemsetAsync(S.ctl, 0, SC_COUNT * 4, s));
+    BB_HIP(hipMemsetAsync(S.busy, 0, (size_t)S.G * 8, s));
+    const uint32_t used = std::min(h.cap_nodes, h.ctr[C_NODES]);
+    hipLaunchKernelGGL(k_sys_init, dim3((used + 255) / 256), dim3(256), 0, s, (const NodeHdr*)h.node_hdr, used, S.mail, S.sent, S.up);
+    BB_HIP(hipGetLastError());
+    return BBH_OK;
+}
 
 // Run the insertion kernel over all jobs, ONE WORKGROUP PER TREE in a single launch (independent
 // trees - multiround shards - run concurrently on different CUs), relaunching the unfinished
@@ -3137,6 +3235,29 @@ int run_insert_multi(std::vector<Job>& jobs, hipStream_t s) {
                         if (jobs[active[a]].old_left == 0 && harr[a].n_elems > max_old) { harr[a].n_elems = max_old; recopy = true; }
                 }
             }
+            // The level-systolic kernel (bb_tree_sys.inc): ONE tree over many workgroups.  BBHIP_SYS=1: whenever the shape allows;
+            // default: where the pipelined kernel has nothing to offer - it asked for its multi-level instance (informative levels
+            // above the leaf-parents at bf 50) or refused the shape (bf 254) and the steady-state kernel would take the stretch.
+            int64_t sys_n = 0;
+            if (single && fk != nullptr && f_packed && !prof_phases && sys_mode() != 0) {
+                Job& sj = jobs[active[0]];
+                bbh_tree* st = sj.t;
+                const int levels = (int)st->h.ctr[C_DEPTH];
+                const bool shape_ok = levels >= 2 && levels <= SYS_MAXLVL && st->gc_runs == 0 && harr[0].n_elems < (1ll << 31) && st->sys_off_left == 0;
+                if (shape_ok) {
+                    if (sys_mode() == 1) sys_n = harr[0].n_elems;
+                    else if (all254 && sj.old_left > 0) sys_n = harr[0].n_elems;
+                    else if (all50 && st->pipe_ml) sys_n = std::min<int64_t>(harr[0].n_elems, 1ll << 17);
+                }
+                if (sys_n > 0) {
+                    pk = nullptr;
+                    rc = sys_prepare(st, s);
+                    if (rc != BBH_OK) break;
+                    harr[0] = st->h;  // (the pools may have grown)
+                    harr[0].n_elems = sys_n;
+                    recopy = true;
+                }
+            }
             if (!pipe_possible && !single) {
                 // (the attempt is over: nobody comes back to the pipeline, the stretches are the rest of the input)
                 for (size_t a = 0; a < active.size(); ++a) {
@@ -3168,7 +3289,12 @@ int run_insert_multi(std::vector<Job>& jobs, hipStream_t s) {
                 e = hipMemcpyAsync(dptr, harr.data(), active.size() * sizeof(TreeDev), hipMemcpyHostToDevice, s);
                 if (e != hipSuccess) { rc = bb::fail(BBH_ERR_HIP, "H2D: %s", hipGetErrorString(e)); break; }
             }
-            if (pk != nullptr) {
+            if (sys_n > 0) {
+                log_kernel = "sys";
+                const SysDev& S = jobs[active[0]].t->sys;
+                if (all50) hipLaunchKernelGGL(k_tree_sys<KS50>, dim3((unsigned)S.G), block, KS50::o.total + SYS_LDS_BYTES, s, dptr, S);
+                else hipLaunchKernelGGL(k_tree_sys<KS254>, dim3((unsigned)S.G), block, KS254::o.total + SYS_LDS_BYTES, s, dptr, S);
+            } else if (pk != nullptr) {
                 log_kernel = "pipe";
                 static const bool pipe_audit = getenv("BBHIP_PIPE_AUDIT") != nullptr;
                 static const bool pipe_phases = getenv("BBHIP_PIPE_PHASES") != nullptr || pipe_audit;
@@ -3201,7 +3327,7 @@ int run_insert_multi(std::vector<Job>& jobs, hipStream_t s) {
             e = hipGetLastError();
         }
         if (prof_tok != (size_t)-1)
-            bb::prof_rename(prof_tok, log_kernel[0] == 'p' ? "tree_insert/pipe" : (log_kernel[0] == 'f' ? "tree_insert/fast" : "tree_insert/complete"));
+            bb::prof_rename(prof_tok, log_kernel[0] == 's' ? "tree_insert/sys" : (log_kernel[0] == 'p' ? "tree_insert/pipe" : (log_kernel[0] == 'f' ? "tree_insert/fast" : "tree_insert/complete")));
         if (e == hipSuccess) e = hipMemcpyAsync(harr.data(), dptr, active.size() * sizeof(TreeDev), hipMemcpyDeviceToHost, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);
         if (e != hipSuccess) { rc = bb::fail(BBH_ERR_HIP, "tree_insert: %s", hipGetErrorString(e)); break; }
@@ -3252,13 +3378,33 @@ int run_insert_multi(std::vector<Job>& jobs, hipStream_t s) {
             std::memcpy(h.rprof, back.rprof, sizeof(h.rprof));
             j.done += back.processed;
             {
-                const int kk = log_kernel[0] == 'p' ? 0 : (log_kernel[0] == 'f' ? 1 : 2);
+                const bool was_sys = log_kernel[0] == 's';
+                const int kk = (log_kernel[0] == 'p' || was_sys) ? 0 : (log_kernel[0] == 'f' ? 1 : 2);  // (the systolic kernel counts with the pipelined ones)
                 t->kcount[kk] += (uint64_t)back.processed;
                 t->kcount[3 + kk] += 1;
+                if (was_sys) {
+                    t->syscount[0] += (uint64_t)back.processed;
+                    t->syscount[1] += 1;
+                    if (back.stop_reason == STOP_SYS_RELAUNCH) t->syscount[2] += 1;
+                    t->syscount[3] = (uint64_t)t->sys.G;
+                    std::vector<unsigned long long> busy((size_t)t->sys.G);
+                    if (hipMemcpy(busy.data(), t->sys.busy, busy.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+                        for (unsigned long long b : busy) t->syscount[4] += b;
+                        t->syscount[5] += busy[0];
+                        unsigned long long mx = 0;
+                        for (size_t q = 1; q < busy.size(); ++q) mx = std::max(mx, busy[q]);
+                        t->syscount[6] += mx;
+                    } else {
+                        (void)hipGetLastError();
+                    }
+                    if (back.stop_reason == STOP_SYS_UNSUPPORTED) t->syscount[7] += 1;
+                    if (sys_mode() == 2 && back.stop_reason == STOP_DONE && t->h.bf == 50 && back.processed > 0) t->pipe_ml = false;  // (a stint is over: the single-level instance looks at the tree again)
+                }
                 if (back.stop_reason == STOP_PIPE_UNSUPPORTED) t->kcount[6] += 1;
                 if (back.stop_reason == STOP_NODES || back.stop_reason == STOP_CF8 || back.stop_reason == STOP_CF16 || back.stop_reason == STOP_CF32) t->kcount[7] += 1;
             }
             if (j.old_left > 0) j.old_left = std::max<int64_t>(0, j.old_left - back.processed);
+            if (t->sys_off_left > 0 && log_kernel[0] != 's') t->sys_off_left = std::max<int64_t>(0, t->sys_off_left - back.processed);
             if (prof_tok != (size_t)-1) bb::prof_units(prof_tok, back.processed);  // elements this launch inserted
             j.stalls = (back.processed == 0 && back.stop_reason != STOP_PIPE_UNSUPPORTED && back.stop_reason != STOP_PIPE_NEEDS_ML) ? j.stalls + 1 : 0;
             if (j.stalls > 3) { rc = bb::fail(BBH_ERR_CAPACITY, "tree engine made no progress (stop reason %d)", back.stop_reason); break; }
@@ -3297,6 +3443,8 @@ int run_insert_multi(std::vector<Job>& jobs, hipStream_t s) {
                     t->unsup_stretch = t->unsup_stretch == 0 ? 8192 : (back.processed > 0 ? 1024 : std::min<int64_t>(t->unsup_stretch * 2, BBH_UNSUP_CAP));
                     j.old_left = t->unsup_stretch;
                     break;
+                case STOP_SYS_RELAUNCH: break;  // the root was split: the same kernel again, one level more
+                case STOP_SYS_UNSUPPORTED: t->sys_off_left = 1 << 16; break;
                 case STOP_PIPE_NEEDS_ML: t->pipe_ml = true; break;  // relaunched at once, with the multi-level instance
                 case STOP_PIPE_PREFERS_SL: t->pipe_ml = false; break;  // ... and back (after a stint of >= PIPE_ML_STINT elements)
                 case STOP_INTERNAL: {
@@ -3400,6 +3548,7 @@ extern "C" int bbh_tree_destroy(bbh_tree* t) {
     if (t->d_tol) (void)bb::dev_free(t->d_tol);
     if (t->d_chain_nodes) (void)bb::dev_free(t->d_chain_nodes);
     if (t->d_chain_rows) (void)bb::dev_free(t->d_chain_rows);
+    sys_free(t);
     delete t;
     return BBH_OK;
 }
@@ -3798,6 +3947,14 @@ extern "C" int bbh_tree_gather_centroids(bbh_tree* t, const int64_t* positions, 
 extern "C" int bbh_tree_kernel_counts(bbh_tree* t, uint64_t* out8) {
     if (!t || !out8) return bb::fail(BBH_ERR_INVALID, "null argument");
     for (int i = 0; i < 8; ++i) out8[i] = t->kcount[i];
+    return BBH_OK;
+}
+
+// the level-systolic kernel's record: elements, launches, relaunches after a root split, workgroups of the last launch, busy
+// shader cycles summed over all workgroups / of workgroup 0 (the root's owner) / of the busiest other workgroup, refusals
+extern "C" int bbh_tree_sys_counts(bbh_tree* t, uint64_t* out8) {
+    if (!t || !out8) return bb::fail(BBH_ERR_INVALID, "null argument");
+    for (int i = 0; i < 8; ++i) out8[i] = t->syscount[i];
     return BBH_OK;
 }
 

@@ -215,6 +215,15 @@ int bbh_tree_stats(bbh_tree* t, uint64_t* out8);
  * ended because a pool was exhausted (the host grew it and relaunched). */
 int bbh_tree_kernel_counts(bbh_tree* t, uint64_t* out8);
 
+/* The level-systolic kernel (one tree over many workgroups: every node has an owner workgroup, elements flow down
+ * the levels through one-way rings; the reference's order per node - bitbirch.py:305-357 - by construction; its
+ * elements also count as "pipelined" in bbh_tree_kernel_counts): [0] elements it inserted, [1] its launches,
+ * [2] relaunches after a root split, [3] workgroups of the last launch, [4] shader cycles its workgroups spent on
+ * elements (not waiting), summed, [5] those of workgroup 0 (the root's owner), [6] of the busiest other
+ * workgroup (summed over launches), [7] launches it refused (a shape it does not take).
+ * BBHIP_SYS=0 switches it off, =1 uses it wherever the shape allows, unset: where the other kernels are weakest. */
+int bbh_tree_sys_counts(bbh_tree* t, uint64_t* out8);
+
 /* What the tree holds in HBM and what its node storage did (tests, tools/config45.py, bench.py):
  * [0] bytes of the node pools (capacity), [1] bytes of their used part, [2] bytes of the uint8 / uint16 / uint32
  * cluster-feature pools (capacity), [3] largest sum of this tree's allocations so far (a pool that is being regrown
