@@ -2944,8 +2944,8 @@ int configure(bbh_tree* t, int32_t bf, int32_t n_features) {
                 return bb::fail(BBH_ERR_NO_DEVICE, "device %d offers %d bytes of LDS per workgroup, the tree kernels need %u", t->device, cap,
                                 pipe_layout(254).total);
             }
-            BB_HIP(hipFuncSetAttribute((const void*)k_tree_sys<KS50>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(KS50::o.total + SYS_LDS_BYTES)));
-            BB_HIP(hipFuncSetAttribute((const void*)k_tree_sys<KS254>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(KS254::o.total + SYS_LDS_BYTES)));
+            BB_HIP(hipFuncSetAttribute((const void*)k_tree_sys<KS50>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(KS50::o.total + sys_lds_bytes<KS50>())));
+            BB_HIP(hipFuncSetAttribute((const void*)k_tree_sys<KS254>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(KS254::o.total + sys_lds_bytes<KS254>())));
             attr_done_dev[di] = true;
         }
     }
@@ -3292,8 +3292,8 @@ int run_insert_multi(std::vector<Job>& jobs, hipStream_t s) {
             if (sys_n > 0) {
                 log_kernel = "sys";
                 const SysDev& S = jobs[active[0]].t->sys;
-                if (all50) hipLaunchKernelGGL(k_tree_sys<KS50>, dim3((unsigned)S.G), block, KS50::o.total + SYS_LDS_BYTES, s, dptr, S);
-                else hipLaunchKernelGGL(k_tree_sys<KS254>, dim3((unsigned)S.G), block, KS254::o.total + SYS_LDS_BYTES, s, dptr, S);
+                if (all50) hipLaunchKernelGGL(k_tree_sys<KS50>, dim3((unsigned)S.G), block, KS50::o.total + sys_lds_bytes<KS50>(), s, dptr, S);
+                else hipLaunchKernelGGL(k_tree_sys<KS254>, dim3((unsigned)S.G), block, KS254::o.total + sys_lds_bytes<KS254>(), s, dptr, S);
             } else if (pk != nullptr) {
                 log_kernel = "pipe";
                 static const bool pipe_audit = getenv("BBHIP_PIPE_AUDIT") != nullptr;
