@@ -2946,6 +2946,8 @@ int configure(bbh_tree* t, int32_t bf, int32_t n_features) {
             }
             BB_HIP(hipFuncSetAttribute((const void*)k_tree_sys<KS50>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(KS50::o.total + sys_lds_bytes<KS50>())));
             BB_HIP(hipFuncSetAttribute((const void*)k_tree_sys<KS254>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(KS254::o.total + sys_lds_bytes<KS254>())));
+            BB_HIP(hipFuncSetAttribute((const void*)k_tree_sys<KS50, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(KS50::o.total + sys_lds_bytes<KS50>())));
+            BB_HIP(hipFuncSetAttribute((const void*)k_tree_sys<KS254, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(KS254::o.total + sys_lds_bytes<KS254>())));
             attr_done_dev[di] = true;
         }
     }
@@ -3055,15 +3057,15 @@ static void sys_plan(const TreeDev& h, SysDev& S) {
         int cnt;
         if (l == 0) cnt = 1;
         else if (l == levels - 1) cnt = env_leaf > 0 ? env_leaf : 64;
-        else cnt = env_int > 0 ? env_int : (h.bf >= 128 ? 32 : 16);
+        else cnt = env_int > 0 ? env_int : (h.bf >= 128 ? 64 : 16);  // (bf 254: one mirrored node per owner - as many owners as a level has nodes)
         cnt = std::min(cnt, SYS_MAXPROD);
+        while (cnt & (cnt - 1)) cnt &= cnt - 1;  // a power of two (sys_owner_idx)
         S.lvl_first[l] = first;
         S.lvl_count[l] = cnt;
         first += cnt;
     }
     S.G = first;
-    S.R = 1024;
-    S.qmax = 384;
+    S.qmax = 384;  // (< SYS_R: no ring can overflow)
 }
 
 // (re)allocate what the plan and the node pool's size need; zero the rings and control words, initialise the mailboxes
@@ -3081,13 +3083,15 @@ static int sys_prepare(bbh_tree* t, hipStream_t s) {
         BB_TRY(grow_cf(t, 1, clamp30((uint64_t)h.ctr[C_N16] + q + 64)));
         BB_TRY(grow_cf(t, 2, clamp30((uint64_t)h.ctr[C_N32] + q * 2 * (depth + 2) + room / 4 + 16)));
     }
-    const size_t ring_bytes = (size_t)S.G * SYS_MAXPROD * (size_t)S.R * 16;
+    const size_t ring_bytes = (size_t)S.G * SYS_MAXPROD * (size_t)SYS_R * 16;
+    S.launch_id = (S.launch_id + 1u) & 0x7FFFu;
+    if (S.launch_id == 0) S.launch_id = 1;
     if (ring_bytes > t->sys_ring_bytes || S.G > t->sys_G_alloc) {
         if (S.rings) bb::dev_free(S.rings);
         if (S.busy) bb::dev_free(S.busy);
         S.rings = nullptr; S.busy = nullptr;
         BB_HIP(bb::dev_alloc(&S.rings, ring_bytes));
-        BB_HIP(bb::dev_alloc(&S.busy, (size_t)S.G * 8 + 64));
+        BB_HIP(bb::dev_alloc(&S.busy, (size_t)S.G * 13 * 8 + 64));
         t->sys_ring_bytes = ring_bytes;
         t->sys_G_alloc = S.G;
     }
@@ -3104,7 +3108,7 @@ static int sys_prepare(bbh_tree* t, hipStream_t s) {
     }
     BB_HIP(hipMemsetAsync(S.rings, 0, ring_bytes, s));
     BB_HIP(hipMemsetAsync(S.ctl, 0, SC_COUNT * 4, s));
-    BB_HIP(hipMemsetAsync(S.busy, 0, (size_t)S.G * 8, s));
+    BB_HIP(hipMemsetAsync(S.busy, 0, (size_t)S.G * 13 * 8, s));
     const uint32_t used = std::min(h.cap_nodes, h.ctr[C_NODES]);
     hipLaunchKernelGGL(k_sys_init, dim3((used + 255) / 256), dim3(256), 0, s, (const NodeHdr*)h.node_hdr, used, S.mail, S.sent, S.up);
     BB_HIP(hipGetLastError());
@@ -3292,7 +3296,11 @@ int run_insert_multi(std::vector<Job>& jobs, hipStream_t s) {
             if (sys_n > 0) {
                 log_kernel = "sys";
                 const SysDev& S = jobs[active[0]].t->sys;
-                if (all50) hipLaunchKernelGGL(k_tree_sys<KS50>, dim3((unsigned)S.G), block, KS50::o.total + sys_lds_bytes<KS50>(), s, dptr, S);
+                static const bool sys_phases = getenv("BBHIP_SYS_PHASES") != nullptr;
+                if (sys_phases) {
+                    if (all50) hipLaunchKernelGGL((k_tree_sys<KS50, true>), dim3((unsigned)S.G), block, KS50::o.total + sys_lds_bytes<KS50>(), s, dptr, S);
+                    else hipLaunchKernelGGL((k_tree_sys<KS254, true>), dim3((unsigned)S.G), block, KS254::o.total + sys_lds_bytes<KS254>(), s, dptr, S);
+                } else if (all50) hipLaunchKernelGGL(k_tree_sys<KS50>, dim3((unsigned)S.G), block, KS50::o.total + sys_lds_bytes<KS50>(), s, dptr, S);
                 else hipLaunchKernelGGL(k_tree_sys<KS254>, dim3((unsigned)S.G), block, KS254::o.total + sys_lds_bytes<KS254>(), s, dptr, S);
             } else if (pk != nullptr) {
                 log_kernel = "pipe";
@@ -3398,6 +3406,26 @@ int run_insert_multi(std::vector<Job>& jobs, hipStream_t s) {
                         (void)hipGetLastError();
                     }
                     if (back.stop_reason == STOP_SYS_UNSUPPORTED) t->syscount[7] += 1;
+                    static const bool sys_phases_log = getenv("BBHIP_SYS_PHASES") != nullptr;
+                    if (sys_phases_log && back.processed > 0) {
+                        // (phase-timer instance) cycles per element of the internal step: the root's owner, and the busiest owner of every other level
+                        std::vector<unsigned long long> ph((size_t)t->sys.G * 13);
+                        if (hipMemcpy(ph.data(), t->sys.busy, ph.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+                            static const char* names[12] = {"lookup", "compare(hit)", "fill+compare(miss)", "guard", "send", "commit", "rest", "misses", "mailbox-rereads", "reread-spins", "ALONE", "ALONE-wait-cycles"};
+                            for (int l = 0; l < t->sys.levels; ++l) {
+                                int best = t->sys.lvl_first[l];
+                                for (int w = t->sys.lvl_first[l]; w < t->sys.lvl_first[l] + t->sys.lvl_count[l]; ++w)
+                                    if (ph[(size_t)w] > ph[(size_t)best]) best = w;
+                                fprintf(stderr, "[bbhip sys phases] level %d: %d workgroups, busiest wg %d: busy %.0f cycles per launch element (%lld elements)", l, t->sys.lvl_count[l], best,
+                                        (double)ph[(size_t)best] / (double)back.processed, (long long)back.processed);
+                                if (l < t->sys.levels - 1)
+                                    for (int i = 0; i < 12; ++i) fprintf(stderr, " %s %.0f", names[i], (double)ph[(size_t)t->sys.G + (size_t)best * 12 + i] / ((i >= 7 && i <= 10) ? 1.0 : (double)back.processed));
+                                fprintf(stderr, "\n");
+                            }
+                        } else {
+                            (void)hipGetLastError();
+                        }
+                    }
                     if (sys_mode() == 2 && back.stop_reason == STOP_DONE && t->h.bf == 50 && back.processed > 0) t->pipe_ml = false;  // (a stint is over: the single-level instance looks at the tree again)
                 }
                 if (back.stop_reason == STOP_PIPE_UNSUPPORTED) t->kcount[6] += 1;
