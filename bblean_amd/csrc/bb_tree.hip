@@ -40,6 +40,7 @@
 // ingest of host / file-backed rows (HostSlabs) and the leaf export kernels.
 #include "bb_common.h"
 
+#include <atomic>
 #include <chrono>
 
 #include <rocprim/device/device_scan.hpp>
@@ -2574,6 +2575,8 @@ struct bbh_tree {
     int sys_G_alloc = 0;
     uint64_t syscount[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int64_t sys_off_left = 0;  // elements the other kernels take after the systolic one refused the tree
+    bool sys_pref = false;     // (default policy) this tree goes to the systolic kernel: the pipelined one asked for its multi-level
+                               // instance / refused the shape AND the root's centroids are informative (sys_root_informative)
 };
 
 namespace {
@@ -3028,8 +3031,22 @@ struct Job {
 };
 
 // ---- the level-systolic kernel's work area and launch plan (bb_tree_sys.inc) --------------------------------------------
+// the words workgroups talk through: uncached device memory (bb_tree_sys.inc, "Memory model")
+template <typename T>
+static hipError_t sys_alloc_uc(T** p, size_t bytes) {
+    hipError_t e = hipExtMallocWithFlags((void**)p, bytes, hipDeviceMallocUncached);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        bb::dev_trim();
+        e = hipExtMallocWithFlags((void**)p, bytes, hipDeviceMallocUncached);
+    }
+    return e;
+}
 void sys_free(bbh_tree* t) {
-    void* ptrs[] = {t->sys.rings, t->sys.mail, t->sys.sent, t->sys.up, t->sys.ctl, t->sys.busy};
+    void* uc[] = {t->sys.rings, t->sys.mail, t->sys.sent, t->sys.up, t->sys.ctl};
+    for (void* q : uc)
+        if (q) (void)hipFree(q);
+    void* ptrs[] = {t->sys.laste, t->sys.busy};
     for (void* q : ptrs)
         if (q) bb::dev_free(q);
     t->sys = SysDev{};
@@ -3044,6 +3061,25 @@ static int sys_mode() {
     const char* v = getenv("BBHIP_SYS");
     if (v == nullptr || v[0] == '\0' || std::strcmp(v, "auto") == 0) return 2;
     return std::strcmp(v, "0") == 0 ? 0 : 1;
+}
+
+// Are the root's centroids informative (some row's popcount non-zero)?  Trees over sparse / weakly clustered rows keep
+// all-zero centroids in their upper levels (every similarity 0, np.argmax -> row 0): one exact level, the shape the pipelined
+// kernel was built for (S-fake: 460 k/s there, 274 k/s here).  Trees over real-fingerprint-like rows compare at every level:
+// that is what the systolic kernel is for (zipf / hier: 122-131 k/s there, 357-379 k/s here).  Two small blocking copies, made
+// only when the pipelined kernel has just handed the tree over.
+static bool sys_root_informative(bbh_tree* t) {
+    const TreeDev& h = t->h;
+    const uint32_t root = h.ctr[C_ROOT];
+    NodeHdr hd{};
+    if (hipMemcpy(&hd, h.node_hdr + root, sizeof(hd), hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return false; }
+    const uint32_t len = std::min<uint32_t>(hd.len, (uint32_t)h.bf + 1);
+    if (len == 0 || (hd.leaf & HW_LEAF)) return false;
+    std::vector<uint32_t> cards(len);
+    if (hipMemcpy(cards.data(), h.node_card + (size_t)root * NG, (size_t)len * 4, hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return false; }
+    for (uint32_t cd : cards)
+        if (cd != 0) return true;
+    return false;
 }
 
 // workgroups per tree level: level 0 is workgroup 0 (the root), the last level the leaf owners
@@ -3065,6 +3101,18 @@ static void sys_plan(const TreeDev& h, SysDev& S) {
         first += cnt;
     }
     S.G = first;
+    // every workgroup has to be RESIDENT (one per CU: the kernel takes most of a CU's LDS) - a workgroup that waits for a CU while
+    // the others wait for its answers is a deadlock (found by the randomised suite: five levels at bf 254 came to 257 workgroups)
+    while (S.G > 224) {
+        first = 0;
+        for (int l = 0; l < levels && l < SYS_MAXLVL; ++l) {
+            if (l > 0 && l < levels - 1 && S.lvl_count[l] > 8) S.lvl_count[l] /= 2;
+            S.lvl_first[l] = first;
+            first += S.lvl_count[l];
+        }
+        if (first == S.G) break;
+        S.G = first;
+    }
     S.qmax = 384;  // (< SYS_R: no ring can overflow)
 }
 
@@ -3084,35 +3132,73 @@ static int sys_prepare(bbh_tree* t, hipStream_t s) {
         BB_TRY(grow_cf(t, 2, clamp30((uint64_t)h.ctr[C_N32] + q * 2 * (depth + 2) + room / 4 + 16)));
     }
     const size_t ring_bytes = (size_t)S.G * SYS_MAXPROD * (size_t)SYS_R * 16;
-    S.launch_id = (S.launch_id + 1u) & 0x7FFFu;
-    if (S.launch_id == 0) S.launch_id = 1;
+    {
+        static std::atomic<uint32_t> g_sys_launch{0};  // (process-wide: a new tree may inherit another tree's ring memory)
+        S.launch_id = (g_sys_launch.fetch_add(1u) + 1u) & 0x7FFFFFFFu;
+        if (S.launch_id == 0) S.launch_id = (g_sys_launch.fetch_add(1u) + 1u) & 0x7FFFFFFFu;
+    }
     if (ring_bytes > t->sys_ring_bytes || S.G > t->sys_G_alloc) {
-        if (S.rings) bb::dev_free(S.rings);
+        if (S.rings) (void)hipFree(S.rings);
         if (S.busy) bb::dev_free(S.busy);
         S.rings = nullptr; S.busy = nullptr;
-        BB_HIP(bb::dev_alloc(&S.rings, ring_bytes));
-        BB_HIP(bb::dev_alloc(&S.busy, (size_t)S.G * 13 * 8 + 64));
+        BB_HIP(sys_alloc_uc(&S.rings, ring_bytes));
+        BB_HIP(bb::dev_alloc(&S.busy, (size_t)S.G * (15 * 8 + 3 * SYS_MAXPROD * 4) + 64));
         t->sys_ring_bytes = ring_bytes;
         t->sys_G_alloc = S.G;
     }
-    if (!S.ctl) BB_HIP(bb::dev_alloc(&S.ctl, SC_COUNT * 4));
+    if (!S.ctl) BB_HIP(sys_alloc_uc(&S.ctl, SC_COUNT * 4));
     if (h.cap_nodes > t->sys_cap_nodes || !S.mail) {
-        if (S.mail) bb::dev_free(S.mail);
-        if (S.sent) bb::dev_free(S.sent);
-        if (S.up) bb::dev_free(S.up);
-        S.mail = nullptr; S.sent = nullptr; S.up = nullptr;
-        BB_HIP(bb::dev_alloc(&S.mail, (size_t)h.cap_nodes * 8 + 64));
-        BB_HIP(bb::dev_alloc(&S.sent, (size_t)h.cap_nodes * 4 + 64));
-        BB_HIP(bb::dev_alloc(&S.up, (size_t)h.cap_nodes * 8 + 64));
+        if (S.mail) (void)hipFree(S.mail);
+        if (S.sent) (void)hipFree(S.sent);
+        if (S.up) (void)hipFree(S.up);
+        if (S.laste) bb::dev_free(S.laste);
+        S.mail = nullptr; S.sent = nullptr; S.up = nullptr; S.laste = nullptr;
+        BB_HIP(bb::dev_alloc(&S.laste, (size_t)h.cap_nodes * 4 + 64));
+        BB_HIP(sys_alloc_uc(&S.mail, (size_t)h.cap_nodes * 8 + 64));
+        BB_HIP(sys_alloc_uc(&S.sent, (size_t)h.cap_nodes * 4 + 64));
+        BB_HIP(sys_alloc_uc(&S.up, (size_t)h.cap_nodes * 8 + 64));
         t->sys_cap_nodes = h.cap_nodes;
     }
     BB_HIP(hipMemsetAsync(S.rings, 0, ring_bytes, s));
     BB_HIP(hipMemsetAsync(S.ctl, 0, SC_COUNT * 4, s));
-    BB_HIP(hipMemsetAsync(S.busy, 0, (size_t)S.G * 13 * 8, s));
+    BB_HIP(hipMemsetAsync(S.busy, 0, (size_t)S.G * (15 * 8 + 3 * SYS_MAXPROD * 4), s));
     const uint32_t used = std::min(h.cap_nodes, h.ctr[C_NODES]);
-    hipLaunchKernelGGL(k_sys_init, dim3((used + 255) / 256), dim3(256), 0, s, (const NodeHdr*)h.node_hdr, used, S.mail, S.sent, S.up);
+    hipLaunchKernelGGL(k_sys_init, dim3((used + 255) / 256), dim3(256), 0, s, (const NodeHdr*)h.node_hdr, used, S.mail, S.sent, S.up, S.laste);
     BB_HIP(hipGetLastError());
     return BBH_OK;
+}
+
+// ids handed out by a launch of the systolic kernel, renumbered into the sequential engines' order (bb_tree_sys.inc)
+static int sys_renumber(bbh_tree* t, uint32_t* out_leaf, uint32_t n, uint32_t base, uint32_t nnew, hipStream_t s) {
+    if (out_leaf == nullptr || n == 0 || nnew == 0) return BBH_OK;
+    uint32_t *creator = nullptr, *flag = nullptr, *rank = nullptr, *map = nullptr;
+    void* tmp = nullptr;
+    auto body = [&]() -> int {
+        BB_HIP(bb::dev_alloc(&creator, (size_t)nnew * 4 + 64));
+        BB_HIP(bb::dev_alloc(&flag, (size_t)n * 4 + 64));
+        BB_HIP(bb::dev_alloc(&rank, (size_t)n * 4 + 64));
+        BB_HIP(bb::dev_alloc(&map, (size_t)nnew * 4 + 64));
+        BB_HIP(hipMemsetAsync(creator, 0xFF, (size_t)nnew * 4, s));
+        const dim3 ge((n + 255) / 256), gi((nnew + 255) / 256), blk(256);
+        hipLaunchKernelGGL(k_sys_creator, ge, blk, 0, s, (const uint32_t*)out_leaf, n, base, creator);
+        hipLaunchKernelGGL(k_sys_flag, ge, blk, 0, s, (const uint32_t*)out_leaf, n, base, (const uint32_t*)creator, flag);
+        size_t tmp_bytes = 0;
+        BB_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, flag, rank, 0u, (size_t)n, rocprim::plus<uint32_t>(), s));
+        BB_HIP(bb::dev_alloc(&tmp, tmp_bytes + 16));
+        BB_HIP(rocprim::exclusive_scan(tmp, tmp_bytes, flag, rank, 0u, (size_t)n, rocprim::plus<uint32_t>(), s));
+        hipLaunchKernelGGL(k_sys_map, gi, blk, 0, s, (const uint32_t*)creator, (const uint32_t*)rank, nnew, base, map);
+        hipLaunchKernelGGL(k_sys_apply_out, ge, blk, 0, s, out_leaf, n, base, nnew, (const uint32_t*)map);
+        const uint32_t used = std::min(t->h.cap_nodes, t->h.ctr[C_NODES]);
+        hipLaunchKernelGGL(k_sys_apply_rows, dim3((used + 3) / 4), blk, 0, s, (const NodeHdr*)t->h.node_hdr, t->h.node_rm, used, base, nnew, (const uint32_t*)map);
+        BB_HIP(hipGetLastError());
+        BB_HIP(hipStreamSynchronize(s));
+        return BBH_OK;
+    };
+    const int rc = body();
+    void* ptrs[] = {creator, flag, rank, map, tmp};
+    for (void* q : ptrs)
+        if (q) bb::dev_free(q);
+    return rc;
 }
 
 // Run the insertion kernel over all jobs, ONE WORKGROUP PER TREE in a single launch (independent
@@ -3160,6 +3246,7 @@ int run_insert_multi(std::vector<Job>& jobs, hipStream_t s) {
         }
         TreeDev* dptr = single ? jobs[0].t->d : darr;
         size_t prof_tok = (size_t)-1;
+        uint32_t sys_ids_before = 0;  // (the systolic kernel: BitFeature ids in use before its launch)
         static const bool launch_log = [] {  // one line per launch on stderr (tools/); unset, empty or "0": off
             const char* v = getenv("BBHIP_LAUNCH_LOG");
             return v != nullptr && v[0] != '\0' && std::strcmp(v, "0") != 0;
@@ -3243,18 +3330,26 @@ int run_insert_multi(std::vector<Job>& jobs, hipStream_t s) {
             // default: where the pipelined kernel has nothing to offer - it asked for its multi-level instance (informative levels
             // above the leaf-parents at bf 50) or refused the shape (bf 254) and the steady-state kernel would take the stretch.
             int64_t sys_n = 0;
-            if (single && fk != nullptr && f_packed && !prof_phases && sys_mode() != 0) {
+            static const bool pipe_diag = getenv("BBHIP_PIPE_AUDIT") != nullptr || getenv("BBHIP_PIPE_PHASES") != nullptr;  // (diagnostics of the pipelined kernel: keep it in charge)
+            if (!pipe_diag && single && fk != nullptr && f_packed && !prof_phases && sys_mode() != 0) {
                 Job& sj = jobs[active[0]];
                 bbh_tree* st = sj.t;
                 const int levels = (int)st->h.ctr[C_DEPTH];
                 const bool shape_ok = levels >= 2 && levels <= SYS_MAXLVL && st->gc_runs == 0 && harr[0].n_elems < (1ll << 31) && st->sys_off_left == 0;
                 if (shape_ok) {
-                    if (sys_mode() == 1) sys_n = harr[0].n_elems;
-                    else if (all254 && sj.old_left > 0) sys_n = harr[0].n_elems;
-                    else if (all50 && st->pipe_ml) sys_n = std::min<int64_t>(harr[0].n_elems, 1ll << 17);
+                    if (sys_mode() == 1) {
+                        sys_n = harr[0].n_elems;
+                    } else {
+                        if (!st->sys_pref && ((all254 && sj.old_left > 0) || (all50 && st->pipe_ml)) && sys_root_informative(st)) st->sys_pref = true;
+                        if (st->sys_pref) {
+                            sj.old_left = 0;  // (the stretch the steady-state kernel was to take is this kernel's, and so is the rest of the call)
+                            sys_n = sj.n - sj.done;
+                        }
+                    }
                 }
                 if (sys_n > 0) {
                     pk = nullptr;
+                    sys_ids_before = st->h.ctr[C_IDS];
                     rc = sys_prepare(st, s);
                     if (rc != BBH_OK) break;
                     harr[0] = st->h;  // (the pools may have grown)
@@ -3391,6 +3486,10 @@ int run_insert_multi(std::vector<Job>& jobs, hipStream_t s) {
                 t->kcount[kk] += (uint64_t)back.processed;
                 t->kcount[3 + kk] += 1;
                 if (was_sys) {
+                    // (ids in the sequential engines' order: bb_tree_sys.inc, "BitFeature ids in the reference's order")
+                    if (back.stop_reason != STOP_INTERNAL && back.ctr[C_IDS] > sys_ids_before)
+                        rc = sys_renumber(t, back.out_leaf, (uint32_t)back.processed, sys_ids_before, back.ctr[C_IDS] - sys_ids_before, s);
+                    if (rc != BBH_OK) break;
                     t->syscount[0] += (uint64_t)back.processed;
                     t->syscount[1] += 1;
                     if (back.stop_reason == STOP_SYS_RELAUNCH) t->syscount[2] += 1;
@@ -3426,7 +3525,6 @@ int run_insert_multi(std::vector<Job>& jobs, hipStream_t s) {
                             (void)hipGetLastError();
                         }
                     }
-                    if (sys_mode() == 2 && back.stop_reason == STOP_DONE && t->h.bf == 50 && back.processed > 0) t->pipe_ml = false;  // (a stint is over: the single-level instance looks at the tree again)
                 }
                 if (back.stop_reason == STOP_PIPE_UNSUPPORTED) t->kcount[6] += 1;
                 if (back.stop_reason == STOP_NODES || back.stop_reason == STOP_CF8 || back.stop_reason == STOP_CF16 || back.stop_reason == STOP_CF32) t->kcount[7] += 1;
@@ -3476,6 +3574,45 @@ int run_insert_multi(std::vector<Job>& jobs, hipStream_t s) {
                 case STOP_PIPE_NEEDS_ML: t->pipe_ml = true; break;  // relaunched at once, with the multi-level instance
                 case STOP_PIPE_PREFERS_SL: t->pipe_ml = false; break;  // ... and back (after a stint of >= PIPE_ML_STINT elements)
                 case STOP_INTERNAL: {
+                    if (log_kernel[0] == 's') {
+                        uint32_t dbg[16] = {0};
+                        (void)hipMemcpy(dbg, t->sys.ctl, sizeof(dbg), hipMemcpyDeviceToHost);
+                        rc = bb::fail(BBH_ERR_HIP, "level-systolic kernel: internal error at bb_tree_sys.inc:%u (node %u child %u sent %u acked %u | fresh sent %u acked %u | level/miss/row %#x element %u)",
+                                      back.giveup_line, dbg[8], dbg[9], dbg[10], dbg[11], dbg[12], dbg[13], dbg[14], dbg[15]);
+                        if (getenv("BBHIP_SYS_DEBUG")) {  // where every workgroup was waiting
+                            std::vector<unsigned long long> stw((size_t)t->sys.G * 15);
+                            if (hipMemcpy(stw.data(), t->sys.busy, stw.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+                                for (int w = 0; w < t->sys.G; ++w) {
+                                    const unsigned long long a = stw[(size_t)t->sys.G * 13 + (size_t)w * 2], b = stw[(size_t)t->sys.G * 13 + (size_t)w * 2 + 1];
+                                    const unsigned kind = (unsigned)(a >> 32);
+                                    if (kind != 4)
+                                        fprintf(stderr, "[bbhip sys state] wg %d: %s node %u child %u want %u (owner index of child in the next level: %u)\n", w,
+                                                kind == 1 ? "guard (pending below the child)" : kind == 2 ? "ALONE (waits for the child)" : kind == 3 ? "drain (all children)" : "busy / never polled",
+                                                (unsigned)a, (unsigned)(b >> 32), (unsigned)b, (unsigned)(((unsigned)(b >> 32)) / node_blocks((uint32_t)t->h.bf + 1)));
+                                }
+                                {   // ring positions: what a producer sent and its consumer has not taken
+                                    std::vector<uint32_t> pos((size_t)t->sys.G * 2 * SYS_MAXPROD);
+                                    if (hipMemcpy(pos.data(), (const uint8_t*)t->sys.busy + (size_t)t->sys.G * 15 * 8, pos.size() * 4, hipMemcpyDeviceToHost) == hipSuccess) {
+                                        for (int l = 0; l + 1 < t->sys.levels; ++l)
+                                            for (int p = 0; p < t->sys.lvl_count[l]; ++p)
+                                                for (int q = 0; q < t->sys.lvl_count[l + 1]; ++q) {
+                                                    const int pw = t->sys.lvl_first[l] + p, cw = t->sys.lvl_first[l + 1] + q;
+                                                    const uint32_t tail = pos[(size_t)pw * 2 * SYS_MAXPROD + SYS_MAXPROD + q], head = pos[(size_t)cw * 2 * SYS_MAXPROD + p];
+                                                    if (tail != head) {
+                                                        unsigned long long ab[2] = {0, 0};
+                                                        (void)hipMemcpy(ab, t->sys.rings + (((size_t)cw * SYS_MAXPROD + (size_t)p) * SYS_R + (head & (SYS_R - 1u))) * 2, 16, hipMemcpyDeviceToHost);
+                                                        fprintf(stderr, "[bbhip sys state] ring wg %d -> wg %d: sent %u taken %u; the slot the consumer is looking at: %016llx %016llx (launch id %u: gen %u alone %u node %u element %u | gen %u launch %u epoch %u)\n",
+                                                                pw, cw, tail, head, ab[0], ab[1], t->sys.launch_id, (unsigned)(ab[0] >> 63), (unsigned)((ab[0] >> 62) & 1), (unsigned)((ab[0] >> 31) & 0x3FFFFFFF),
+                                                                (unsigned)(ab[0] & 0x7FFFFFFF), (unsigned)(ab[1] >> 63), (unsigned)((ab[1] >> 32) & 0x7FFFFFFF), (unsigned)ab[1]);
+                                                    }
+                                                }
+                                    }
+                                }
+                                for (int l = 0; l < t->sys.levels; ++l) fprintf(stderr, "[bbhip sys state] level %d: workgroups %d..%d\n", l, t->sys.lvl_first[l], t->sys.lvl_first[l] + t->sys.lvl_count[l] - 1);
+                            }
+                        }
+                        break;
+                    }
                     const unsigned int line = back.giveup_line;
                     rc = bb::fail(BBH_ERR_HIP, "pipelined kernel: a wait gave up (internal error; first at bb_tree_pipe.inc:%u)", line);
                     break;
@@ -3603,6 +3740,7 @@ extern "C" int bbh_tree_set_merge(bbh_tree* t, int32_t criterion, double toleran
 }
 
 extern "C" int bbh_tree_reset(bbh_tree* t) {
+    if (t) { t->sys_pref = false; t->sys_off_left = 0; }
     if (!t) return bb::fail(BBH_ERR_INVALID, "null tree");
     return init_empty(t);  // pools are kept and reused
 }

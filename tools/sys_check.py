@@ -56,17 +56,18 @@ for name in names:
                 continue
             ch, co = canon(hip._log_leaf), canon(ora._log_leaf)
             same_leaf = bool((ch == co).all())
+            raw_ids = all(bool((np.asarray(a) == np.asarray(b)).all()) for a, b in zip(hip._log_leaf, ora._log_leaf))  # (after the renumbering: the very ids)
             first = int(np.argmax(ch != co)) if not same_leaf else -1
             sh, so = hip._engine.stats()[:7].tolist(), ora._engine.stats()[:7].tolist()
             same_asg = bool((hip.get_assignments() == ora.get_assignments()).all())
             same_cent = bool((np.array(hip.get_centroids()) == np.array(ora.get_centroids())).all())
             same_ids = hip.get_cluster_mol_ids() == ora.get_cluster_mol_ids()
-            ok = same_leaf and sh == so and same_asg and same_cent and same_ids
+            ok = same_leaf and raw_ids and sh == so and same_asg and same_cent and same_ids
             bad += not ok
             kc = hip._engine.kernel_counts().tolist()
             sc = hip._engine.sys_counts().tolist()
             res[mode] = n / dt
-            print(f"{'OK ' if ok else 'BAD'} {name} bf {bf} BBHIP_SYS={mode}: {n / dt:.0f} fps/s (oracle {n / t_ora:.0f}) leaf {same_leaf} (first diff {first}) "
+            print(f"{'OK ' if ok else 'BAD'} {name} bf {bf} BBHIP_SYS={mode}: {n / dt:.0f} fps/s (oracle {n / t_ora:.0f}) leaf {same_leaf} (first diff {first}) ids {raw_ids} "
                   f"asg {same_asg} cent {same_cent} members {same_ids}\n    hip {sh}\n    ora {so}\n    kernel_counts {kc}\n    sys_counts {sc}", flush=True)
         if "1" in res and "0" in res:
             print(f"    speed: systolic {res['1']:.0f} vs default {res['0']:.0f} = {res['1'] / res['0']:.2f}x", flush=True)
