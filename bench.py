@@ -649,6 +649,55 @@ def multi_gpu(args: argparse.Namespace, world: int) -> None:
 
 
 # ------------------------------------------------------------------------------------------------------
+def workgroups_busy(others) -> dict:
+    out = {"headline_kernel": 1, "compute_units": 256}
+    for key, rec in (others or {}).items():
+        so = rec.get("systolic_opt_in") if isinstance(rec, dict) else None
+        if so and "workgroups" in so:
+            out[f"systolic_opt_in_{key}"] = {"workgroups_resident": so["workgroups"], "parallel_workgroups": so["parallel_workgroups"],
+                                             "identical_to_default_path": so["identical_to_default_path"]}
+    return out
+
+
+def systolic_record(BitBirch, rows, default_tree, bf: int, thr: float, device: int, n: int) -> dict:
+    r"""The same rows through the opt-in level-systolic kernel (`BBHIP_SYS=1`: ONE tree over many workgroups,
+    bblean_amd/csrc/bb_tree_sys.inc), checked against the tree the default path has just built from them: labels and engine
+    counters must be identical, or the record says so instead of quoting a rate.  Opt-in because its hand-over between
+    workgroups is not dependable on adversarial shapes yet (profiles/r06/sys_stability.txt); the kernel returns an error rather
+    than a result when its own checks fail, and that is reported here as `error`."""
+    import torch
+
+    prev = os.environ.get("BBHIP_SYS")
+    os.environ["BBHIP_SYS"] = "1"
+    try:
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        st = BitBirch(branching_factor=bf, threshold=thr, merge_criterion="diameter", device=device).fit(rows)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t1
+        sc = [int(v) for v in st._engine.sys_counts()]
+        same = bool((st.get_assignments() == default_tree.get_assignments()).all()) and \
+            [int(v) for v in st._engine.stats()[:7]] == [int(v) for v in default_tree._engine.stats()[:7]]
+        rec = {"identical_to_default_path": same, "seconds": dt, "elements_in_systolic_kernel": sc[0], "launches": sc[1],
+               "relaunches_after_root_splits": sc[2], "workgroups": sc[3],
+               # cycles spent on elements (not waiting), summed over the launches: all workgroups, the root's owner, the busiest
+               # other workgroup; `parallel_workgroups` = all / the busier of the two = how many workgroups' worth of work ran
+               # beside the critical one
+               "busy_cycles": {"all": sc[4], "root_owner": sc[5], "busiest_other": sc[6]},
+               "parallel_workgroups": sc[4] / max(sc[5], sc[6], 1)}
+        if same:
+            rec["fingerprints_per_s"] = n / dt
+        del st
+        return rec
+    except Exception as exc:  # the kernel's own checks gave up: no result, no rate
+        return {"error": str(exc)[:300]}
+    finally:
+        if prev is None:
+            os.environ.pop("BBHIP_SYS", None)
+        else:
+            os.environ["BBHIP_SYS"] = prev
+
+
 def single_gpu(args: argparse.Namespace) -> None:
     import numpy as np
     import torch
@@ -747,6 +796,8 @@ def single_gpu(args: argparse.Namespace) -> None:
                     cb = cpu_baseline(wf[:msamp].cpu().numpy(), wbf, wthr)
                     rec["cpu_baseline"] = {"value": cb["value"], "unit": cb["unit"], "cores": 1, "kind": "port", "rows": msamp}
                     rec["gpu_over_cpu_core"] = rec["fingerprints_per_s"] / cb["value"]
+                if wname in ("hier", "zipf"):
+                    rec["systolic_opt_in"] = systolic_record(BitBirch, wf, wt, wbf, wthr, local_rank, n)
                 others[f"{wname}_bf{wbf}"] = rec
                 del wt
             del wf
@@ -1130,6 +1181,10 @@ def single_gpu(args: argparse.Namespace) -> None:
             "elements_per_launch": units / k_launches,
             "dominant_launch": {"ms": dom_ms, "elements": dom_units,
                                 "achieved_GBps": BYTES_PER_FP * dom_units / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0},
+            # how much of the chip the tree kernels keep busy: the headline's pipelined kernel is ONE workgroup of 256 CUs by
+            # construction (a single tree's insertions are one dependency chain); the opt-in level-systolic kernel spreads one
+            # tree over its levels' owners (other_workloads.*.systolic_opt_in)
+            "workgroups_busy": workgroups_busy(others),
             "by_kernel": by_kernel,
             "last_fit_elements_by_kernel": {"pipe": int(kc[0]), "fast": int(kc[1]), "complete": int(kc[2]),
                                             "unsupported_shape_stops": int(kc[6])},
