@@ -3032,8 +3032,16 @@ struct Job {
 
 // ---- the level-systolic kernel's work area and launch plan (bb_tree_sys.inc) --------------------------------------------
 // the words workgroups talk through: uncached device memory (bb_tree_sys.inc, "Memory model")
+static bool sys_mem_host() {
+    static const bool h = [] { const char* m = getenv("BBHIP_SYS_MEM"); return m && m[0] == 'h'; }();
+    return h;
+}
 template <typename T>
 static hipError_t sys_alloc_uc(T** p, size_t bytes) {
+    if (sys_mem_host()) {  // (experiment: pinned host memory, coherent by construction, every access crosses the fabric)
+        hipError_t eh = hipHostMalloc((void**)p, bytes, hipHostMallocCoherent);
+        return eh;
+    }
     static const unsigned flags = [] {
         const char* m = getenv("BBHIP_SYS_MEM");  // (experiments: "plain" = ordinary device memory, "fine" = fine-grained)
         if (m && m[0] == 'p') return (unsigned)hipDeviceMallocDefault;
@@ -3051,7 +3059,7 @@ static hipError_t sys_alloc_uc(T** p, size_t bytes) {
 void sys_free(bbh_tree* t) {
     void* uc[] = {t->sys.rings, t->sys.mail, t->sys.sent, t->sys.up, t->sys.ctl};
     for (void* q : uc)
-        if (q) (void)hipFree(q);
+        if (q) (void)(sys_mem_host() ? hipHostFree(q) : hipFree(q));
     void* ptrs[] = {t->sys.laste, t->sys.busy};
     for (void* q : ptrs)
         if (q) bb::dev_free(q);
@@ -3149,7 +3157,7 @@ static int sys_prepare(bbh_tree* t, hipStream_t s) {
         if (S.launch_id == 0) S.launch_id = (g_sys_launch.fetch_add(1u) + 1u) & 0x7FFFFFFFu;
     }
     if (ring_bytes > t->sys_ring_bytes || S.G > t->sys_G_alloc) {
-        if (S.rings) (void)hipFree(S.rings);
+        if (S.rings) (void)(sys_mem_host() ? hipHostFree(S.rings) : hipFree(S.rings));
         if (S.busy) bb::dev_free(S.busy);
         S.rings = nullptr; S.busy = nullptr;
         BB_HIP(sys_alloc_uc(&S.rings, ring_bytes));
@@ -3159,9 +3167,9 @@ static int sys_prepare(bbh_tree* t, hipStream_t s) {
     }
     if (!S.ctl) BB_HIP(sys_alloc_uc(&S.ctl, SC_COUNT * 4));
     if (h.cap_nodes > t->sys_cap_nodes || !S.mail) {
-        if (S.mail) (void)hipFree(S.mail);
-        if (S.sent) (void)hipFree(S.sent);
-        if (S.up) (void)hipFree(S.up);
+        if (S.mail) (void)(sys_mem_host() ? hipHostFree(S.mail) : hipFree(S.mail));
+        if (S.sent) (void)(sys_mem_host() ? hipHostFree(S.sent) : hipFree(S.sent));
+        if (S.up) (void)(sys_mem_host() ? hipHostFree(S.up) : hipFree(S.up));
         if (S.laste) bb::dev_free(S.laste);
         S.mail = nullptr; S.sent = nullptr; S.up = nullptr; S.laste = nullptr;
         BB_HIP(bb::dev_alloc(&S.laste, (size_t)h.cap_nodes * 4 + 64));
