@@ -3057,10 +3057,10 @@ static hipError_t sys_alloc_uc(T** p, size_t bytes) {
     return e;
 }
 void sys_free(bbh_tree* t) {
-    void* uc[] = {t->sys.rings, t->sys.mail, t->sys.sent, t->sys.up, t->sys.ctl};
+    void* uc[] = {t->sys.rings, t->sys.mail, t->sys.ctl};
     for (void* q : uc)
         if (q) (void)(sys_mem_host() ? hipHostFree(q) : hipFree(q));
-    void* ptrs[] = {t->sys.laste, t->sys.busy};
+    void* ptrs[] = {t->sys.laste, t->sys.busy, t->sys.sent, t->sys.up, t->sys.acks};
     for (void* q : ptrs)
         if (q) bb::dev_free(q);
     t->sys = SysDev{};
@@ -3168,21 +3168,23 @@ static int sys_prepare(bbh_tree* t, hipStream_t s) {
     if (!S.ctl) BB_HIP(sys_alloc_uc(&S.ctl, SC_COUNT * 4));
     if (h.cap_nodes > t->sys_cap_nodes || !S.mail) {
         if (S.mail) (void)(sys_mem_host() ? hipHostFree(S.mail) : hipFree(S.mail));
-        if (S.sent) (void)(sys_mem_host() ? hipHostFree(S.sent) : hipFree(S.sent));
-        if (S.up) (void)(sys_mem_host() ? hipHostFree(S.up) : hipFree(S.up));
+        if (S.sent) bb::dev_free(S.sent);
+        if (S.up) bb::dev_free(S.up);
         if (S.laste) bb::dev_free(S.laste);
-        S.mail = nullptr; S.sent = nullptr; S.up = nullptr; S.laste = nullptr;
+        if (S.acks) bb::dev_free(S.acks);
+        S.mail = nullptr; S.sent = nullptr; S.up = nullptr; S.laste = nullptr; S.acks = nullptr;
         BB_HIP(bb::dev_alloc(&S.laste, (size_t)h.cap_nodes * 4 + 64));
+        BB_HIP(bb::dev_alloc(&S.acks, (size_t)h.cap_nodes * 4 + 64));
+        BB_HIP(bb::dev_alloc(&S.sent, (size_t)h.cap_nodes * 4 + 64));
+        BB_HIP(bb::dev_alloc(&S.up, (size_t)h.cap_nodes * 8 + 64));
         BB_HIP(sys_alloc_uc(&S.mail, (size_t)h.cap_nodes * 8 + 64));
-        BB_HIP(sys_alloc_uc(&S.sent, (size_t)h.cap_nodes * 4 + 64));
-        BB_HIP(sys_alloc_uc(&S.up, (size_t)h.cap_nodes * 8 + 64));
         t->sys_cap_nodes = h.cap_nodes;
     }
     BB_HIP(hipMemsetAsync(S.rings, 0, ring_bytes, s));
     BB_HIP(hipMemsetAsync(S.ctl, 0, SC_COUNT * 4, s));
     BB_HIP(hipMemsetAsync(S.busy, 0, (size_t)S.G * (15 * 8 + 3 * SYS_MAXPROD * 4), s));
     const uint32_t used = std::min(h.cap_nodes, h.ctr[C_NODES]);
-    hipLaunchKernelGGL(k_sys_init, dim3((used + 255) / 256), dim3(256), 0, s, (const NodeHdr*)h.node_hdr, used, S.mail, S.sent, S.up, S.laste);
+    hipLaunchKernelGGL(k_sys_init, dim3((used + 255) / 256), dim3(256), 0, s, (const NodeHdr*)h.node_hdr, used, S.mail, S.sent, S.up, S.laste, S.acks);
     BB_HIP(hipGetLastError());
     return BBH_OK;
 }
