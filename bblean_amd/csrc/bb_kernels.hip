@@ -109,6 +109,13 @@ hipError_t dev_free_bytes(size_t need, size_t* free_b) {
     return hipMemGetInfo(free_b, &total_b);
 }
 
+// (experiment switch BBHIP_FINE_POOLS=1: every pool of the library in fine-grained device memory - coherent across XCDs by
+// memory type instead of by fences; profiles/r06/sys_stability.txt)
+static hipError_t raw_device_malloc(void** p, size_t bytes) {
+    static const bool fine = [] { const char* v = getenv("BBHIP_FINE_POOLS"); return v && v[0] == '1'; }();
+    return fine ? hipExtMallocWithFlags(p, bytes, hipDeviceMallocFinegrained) : hipMalloc(p, bytes);
+}
+
 hipError_t dev_alloc(void** p, size_t bytes) {
     DevCache& c = dev_cache();
     int dev = 0;
@@ -126,12 +133,12 @@ hipError_t dev_alloc(void** p, size_t bytes) {
             return hipSuccess;
         }
     }
-    e = hipMalloc(p, cls);
+    e = raw_device_malloc(p, cls);
     if (e != hipSuccess) {  // give the cached blocks back to the driver - ours and the host side's - and retry once
         (void)hipGetLastError();
         dev_trim();
         if (void (*cb)(void) = g_pressure_cb.load()) cb();
-        e = hipMalloc(p, cls);
+        e = raw_device_malloc(p, cls);
         if (e != hipSuccess) return e;
     }
     std::lock_guard<std::mutex> g(c.mu);
