@@ -2483,6 +2483,20 @@ __global__ __launch_bounds__(256) void k_gather_leaves(TreeDev* Tp, const uint32
     }
 }
 
+// {id, len, next} of every header that starts a live leaf (build_chain); out == nullptr: count only
+__global__ __launch_bounds__(256) void k_leaf_headers(const NodeHdr* __restrict__ hdr, uint32_t used, uint32_t* count, uint32_t* out, uint32_t cap) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= used) return;
+    const NodeHdr h = hdr[b];
+    if (hw_cap(h.leaf) == 0 || !(h.leaf & HW_LEAF)) return;
+    const uint32_t i = atomicAdd(count, 1u);
+    if (out != nullptr && i < cap) {
+        out[3 * (size_t)i] = b;
+        out[3 * (size_t)i + 1] = h.len;
+        out[3 * (size_t)i + 2] = h.next;
+    }
+}
+
 // ---- compaction of the node pools (gc_nodes, host side; "Node storage" at the top of this file) -------------------
 // Pass 1, one thread per block of the used part of the pool: how many blocks the node that starts here gets in the new
 // pool - 0 for a block that starts no live node; its length rounded up to a block for a node that is sealed already or
@@ -3712,19 +3726,46 @@ int run_insert(bbh_tree* t, const uint8_t* rows_dev, int64_t row_stride, const u
 int build_chain(bbh_tree* t) {
     if (t->chain_valid) return BBH_OK;
     TreeDev& h = t->h;
-    const uint32_t nn = t->lazy_pools ? 0u : h.ctr[C_NODES];  // (a tree that never received anything owns no pools)
-    std::vector<NodeHdr> hdr(nn);
-    if (nn) BB_HIP(hipMemcpy(hdr.data(), h.node_hdr, (size_t)nn * sizeof(NodeHdr), hipMemcpyDeviceToHost));
+    const uint32_t nn = (t->lazy_pools || h.node_hdr == nullptr) ? 0u : h.ctr[C_NODES];  // (a tree that never received anything owns no pools)
+    // Only the headers that start a live LEAF come to the host (the header pool has one entry per block of four
+    // rows, 64 per full-capacity node at bf 254 - copying all of them was 1 GB for a million unsealed nodes): a counting
+    // pass, then {id, len, next} of every such header, sorted by id on the host and walked from the first leaf.
+    struct LeafHdr { uint32_t id, len, next; };
+    std::vector<LeafHdr> lh;
+    if (nn) {
+        uint32_t* d_count = nullptr;
+        BB_HIP(bb::dev_alloc(&d_count, 64));
+        BB_HIP(hipMemset(d_count, 0, 4));
+        hipLaunchKernelGGL(k_leaf_headers, dim3((nn + 255) / 256), dim3(256), 0, 0, (const NodeHdr*)h.node_hdr, nn, d_count, (uint32_t*)nullptr, 0u);
+        uint32_t count = 0;
+        hipError_t e = hipMemcpy(&count, d_count, 4, hipMemcpyDeviceToHost);
+        uint32_t* d_out = nullptr;
+        if (e == hipSuccess && count) e = bb::dev_alloc(&d_out, (size_t)count * 12);
+        if (e == hipSuccess && count) {
+            e = hipMemset(d_count, 0, 4);
+            if (e == hipSuccess) {
+                hipLaunchKernelGGL(k_leaf_headers, dim3((nn + 255) / 256), dim3(256), 0, 0, (const NodeHdr*)h.node_hdr, nn, d_count, d_out, count);
+                lh.resize(count);
+                e = hipMemcpy(lh.data(), d_out, (size_t)count * 12, hipMemcpyDeviceToHost);
+            }
+        }
+        if (d_out) (void)bb::dev_free(d_out);
+        (void)bb::dev_free(d_count);
+        BB_HIP(e);
+        std::sort(lh.begin(), lh.end(), [](const LeafHdr& a, const LeafHdr& b) { return a.id < b.id; });
+    }
     t->chain_nodes.clear();
     t->chain_rows.clear();
     uint32_t nd = h.ctr[C_FIRST_LEAF];
     size_t guard = 0;
-    while (nd != NONE && nd < nn && guard++ <= nn) {  // (nn: blocks - more than there are nodes)
-        for (uint32_t r = 0; r < hdr[nd].len; ++r) {
+    while (nd != NONE && nd < nn && guard++ <= lh.size()) {
+        const auto it = std::lower_bound(lh.begin(), lh.end(), nd, [](const LeafHdr& a, uint32_t id) { return a.id < id; });
+        if (it == lh.end() || it->id != nd) return bb::fail(BBH_ERR_HIP, "leaf chain points at block %u, which starts no live leaf", nd);
+        for (uint32_t r = 0; r < it->len; ++r) {
             t->chain_nodes.push_back(nd);
             t->chain_rows.push_back(r);
         }
-        nd = hdr[nd].next;
+        nd = it->next;
     }
     const size_t k = t->chain_nodes.size();
     if (k > t->d_chain_cap) {

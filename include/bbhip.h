@@ -221,7 +221,8 @@ int bbh_tree_kernel_counts(bbh_tree* t, uint64_t* out8);
  * [2] relaunches after a root split, [3] workgroups of the last launch, [4] shader cycles its workgroups spent on
  * elements (not waiting), summed, [5] those of workgroup 0 (the root's owner), [6] of the busiest other
  * workgroup (summed over launches), [7] launches it refused (a shape it does not take).
- * BBHIP_SYS=0 switches it off, =1 uses it wherever the shape allows, unset: where the other kernels are weakest. */
+ * Opt-in: BBHIP_SYS=1 uses it wherever the shape allows, =auto where the other kernels are weakest (informative root);
+ * unset or 0 (the default): never - its hand-over between workgroups is not dependable yet, DESIGN.md 6s. */
 int bbh_tree_sys_counts(bbh_tree* t, uint64_t* out8);
 
 /* What the tree holds in HBM and what its node storage did (tests, tools/config45.py, bench.py):
