@@ -92,3 +92,21 @@ def test_multi_gpu_plan_fits_the_drivers_window():
                          capture_output=True, text=True, check=True).stdout
     plan = json.loads(out)
     assert plan["world"] == 8 and plan["projected_wall_s"] <= 1200.0 and plan["rows_per_shard_stated"] == 12_500_000
+
+
+def test_workgroups_busy_record():
+    r"""`roofline.workgroups_busy`: the headline kernel is one workgroup; opt-in systolic sub-records are carried over only when
+    they ran (an `error` record has no workgroup figures) and keep their in-process check's verdict."""
+    import bench
+
+    others = {
+        "zipf_bf50": {"fingerprints_per_s": 1.0, "systolic_opt_in": {"workgroups": 97, "parallel_workgroups": 5.5, "identical_to_default_path": True}},
+        "zipf_bf254": {"fingerprints_per_s": 1.0, "systolic_opt_in": {"error": "level-systolic kernel: internal error"}},
+        "ecfp_bf50": {"fingerprints_per_s": 1.0},
+        "headline_other_seeds": {"5000": {"fingerprints_per_s": 1.0}},
+    }
+    out = bench.workgroups_busy(others)
+    assert out["headline_kernel"] == 1 and out["compute_units"] == 256
+    assert out["systolic_opt_in_zipf_bf50"] == {"workgroups_resident": 97, "parallel_workgroups": 5.5, "identical_to_default_path": True}
+    assert "systolic_opt_in_zipf_bf254" not in out and "systolic_opt_in_ecfp_bf50" not in out
+    assert bench.workgroups_busy(None) == {"headline_kernel": 1, "compute_units": 256}
